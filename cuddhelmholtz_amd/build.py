@@ -1,0 +1,90 @@
+"""Builds the native library (HIP kernels + C ABI + host C++ mirror) for gfx950.
+
+`python -m cuddhelmholtz_amd.build` or `build_native()`; hipcc cross-compiles
+without a GPU.  Objects land in build/, the shared library in
+cuddhelmholtz_amd/lib/ (git-ignored, shipped to the GPU box by gpurun).
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+CSRC = ROOT / "cuddhelmholtz_amd" / "csrc"
+LIB_DIR = ROOT / "cuddhelmholtz_amd" / "lib"
+LIB_PATH = LIB_DIR / "libcuddh_amd.so"
+OBJ_DIR = ROOT / "build" / "obj"
+ARCH = "gfx950"
+
+INCLUDES = [ROOT / "include", CSRC / "include", CSRC / "kernels"]
+COMMON = ["-O3", "-std=c++17", "-fPIC", "-DNDEBUG", "-Wall", "-Wno-unused-parameter", "-Wno-unused-function"]
+HIP_FLAGS = ["-x", "hip", f"--offload-arch={ARCH}", "-munsafe-fp-atomics", "-ffp-contract=fast"]
+
+# host sources that contain device code (device lambdas) and must be compiled as HIP
+HIP_HOST_SOURCES = {"capi.cpp"}
+
+
+def hipcc() -> str:
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not Path(exe).exists():
+        raise RuntimeError("hipcc not found")
+    return exe
+
+
+def _sources():
+    hip = sorted((CSRC / "kernels").glob("*.hip"))
+    cpp = sorted((CSRC / "src").glob("*.cpp"))
+    return hip, cpp
+
+
+def _needs_rebuild(obj: Path, src: Path, headers_mtime: float) -> bool:
+    if not obj.exists():
+        return True
+    m = obj.stat().st_mtime
+    return m < src.stat().st_mtime or m < headers_mtime
+
+
+def _compile(src: Path, as_hip: bool, headers_mtime: float, verbose: bool) -> Path:
+    obj = OBJ_DIR / (src.name + ".o")
+    if not _needs_rebuild(obj, src, headers_mtime):
+        return obj
+    cmd = [hipcc(), *COMMON, *[f"-I{p}" for p in INCLUDES]]
+    if as_hip:
+        cmd += HIP_FLAGS
+    cmd += ["-c", str(src), "-o", str(obj)]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"compilation of {src.name} failed:\n{r.stdout}\n{r.stderr}")
+    if verbose and r.stderr.strip():
+        print(r.stderr, file=sys.stderr)
+    return obj
+
+
+def build_native(verbose: bool = False, jobs: int = 6) -> Path:
+    OBJ_DIR.mkdir(parents=True, exist_ok=True)
+    LIB_DIR.mkdir(parents=True, exist_ok=True)
+    headers = [p for d in INCLUDES for p in d.rglob("*.h*")]
+    headers_mtime = max(p.stat().st_mtime for p in headers)
+    hip, cpp = _sources()
+    work = [(s, True) for s in hip] + [(s, s.name in HIP_HOST_SOURCES) for s in cpp]
+    with ThreadPoolExecutor(max_workers=jobs) as pool:
+        objs = list(pool.map(lambda sw: _compile(sw[0], sw[1], headers_mtime, verbose), work))
+    newest = max(o.stat().st_mtime for o in objs)
+    if not LIB_PATH.exists() or LIB_PATH.stat().st_mtime < newest:
+        cmd = [hipcc(), "-shared", f"--offload-arch={ARCH}", "-o", str(LIB_PATH), *map(str, objs)]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build_native(verbose="-v" in sys.argv))

@@ -1,0 +1,55 @@
+// Fused complex Helmholtz operator  [u; v] -> [S u - w^2 M u - w H v ; -(S v - w^2 M v + w H u)].
+// Same mathematics and the same result vector as the example-level composite of
+// reference examples/Helmholtz.hpp:10-81 (2 memsets + 11 launches per apply there);
+// here one plan-based launch pair reads the metrics, the index map and x once.
+#ifndef CUDDH_AMD_HELMHOLTZ_HPP
+#define CUDDH_AMD_HELMHOLTZ_HPP
+
+#include <cstddef>
+
+#include "operator.hpp"
+#include "operators.hpp"
+#include "spaces.hpp"
+
+struct cuddh_helmholtz_plan;
+
+namespace cuddh
+{
+    class HelmholtzOperator : public Operator
+    {
+    public:
+        /// a2x: DEVICE H1 nodal values of a^2(x); ax: DEVICE FaceSpace values of a(x)
+        HelmholtzOperator(double omega, const double *a2x, const double *ax, const H1Space &fem, const FaceSpace &fs);
+        ~HelmholtzOperator();
+
+        HelmholtzOperator(const HelmholtzOperator &) = delete;
+        HelmholtzOperator &operator=(const HelmholtzOperator &) = delete;
+
+        /// y <- A x with x = [u; v], y = [Au; Av] (each of length fem.size())
+        void action(const double *x, double *y) const override;
+        /// not implemented (neither is it in the reference example)
+        void action(double c, const double *x, double *y) const override;
+
+        /// the same result through the separate operators, launch by launch like the reference example
+        void action_unfused(const double *x, double *y) const;
+
+        /// true when the plan-based kernel is in use (false: fell back to the separate operators)
+        bool fused() const { return plan != nullptr; }
+
+        /// bytes per apply: algorithmic (SURVEY 8d formula) or as laid out by the plan
+        std::size_t bytes_per_apply(bool actual) const;
+
+    private:
+        const double omega;
+        const int ndof, fdof;
+        const H1Space &fem;
+        const FaceSpace &fs;
+        StiffnessMatrix S;
+        MassMatrix M;
+        FaceMassMatrix H;
+        mutable host_device_dvec xf, yf;
+        cuddh_helmholtz_plan *plan = nullptr;
+    };
+} // namespace cuddh
+
+#endif

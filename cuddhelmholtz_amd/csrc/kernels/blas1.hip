@@ -1,0 +1,334 @@
+// Level-1 kernels: streaming maps with 16-byte accesses and a deterministic
+// two-stage reduction (wavefront shuffles, then LDS across the four waves of a
+// workgroup, then one wavefront over the per-workgroup partials).
+#include "common.hpp"
+
+using namespace cuddh_k;
+
+namespace
+{
+    constexpr int BLOCK = 256;
+    constexpr int MAX_PARTIALS = 1024;
+
+    template <typename T>
+    struct Pack; // 16-byte vector of T
+    template <>
+    struct Pack<double>
+    {
+        using type = double2;
+        static constexpr int N = 2;
+    };
+    template <>
+    struct Pack<float>
+    {
+        using type = float4;
+        static constexpr int N = 4;
+    };
+    template <>
+    struct Pack<int>
+    {
+        using type = int4;
+        static constexpr int N = 4;
+    };
+
+    inline bool aligned16(const void *p) { return (reinterpret_cast<size_t>(p) & 15) == 0; }
+
+    // ---------------- y = f(x, y) element-wise; F is a functor T(T x, T y)
+    template <typename T, typename F, bool READ_X, bool READ_Y>
+    __global__ void __launch_bounds__(BLOCK) map_kernel(int n, const T *__restrict__ x, T *__restrict__ y, F f, int vectorised)
+    {
+        using V = typename Pack<T>::type;
+        constexpr int N = Pack<T>::N;
+        const int tid = blockIdx.x * BLOCK + threadIdx.x;
+        const int stride = gridDim.x * BLOCK;
+        int done = 0;
+        if (vectorised)
+        {
+            const int nv = n / N;
+            for (int i = tid; i < nv; i += stride)
+            {
+                V xv, yv;
+                if (READ_X)
+                    xv = reinterpret_cast<const V *>(x)[i];
+                if (READ_Y)
+                    yv = reinterpret_cast<const V *>(y)[i];
+                T *xe = reinterpret_cast<T *>(&xv);
+                T *ye = reinterpret_cast<T *>(&yv);
+#pragma unroll
+                for (int c = 0; c < N; ++c)
+                    ye[c] = f(READ_X ? xe[c] : T(0), READ_Y ? ye[c] : T(0));
+                reinterpret_cast<V *>(y)[i] = yv;
+            }
+            done = nv * N;
+        }
+        for (int i = done + tid; i < n; i += stride)
+            y[i] = f(READ_X ? x[i] : T(0), READ_Y ? y[i] : T(0));
+    }
+
+    template <typename T, bool RX, bool RY, typename F>
+    int launch_map(int n, const T *x, T *y, F f, void *stream)
+    {
+        if (n <= 0)
+            return 0;
+        const int vec = aligned16(y) && (!RX || aligned16(x));
+        hipLaunchKernelGGL((map_kernel<T, F, RX, RY>), dim3(stream_grid(n, BLOCK, Pack<T>::N)), dim3(BLOCK), 0, as_stream(stream), n,
+                           x, y, f, vec);
+        return launch_status();
+    }
+
+    // functors
+    template <typename T>
+    struct Axpby
+    {
+        T a, b;
+        __device__ T operator()(T x, T y) const { return a * x + b * y; }
+    };
+    template <typename T>
+    struct Ax
+    {
+        T a;
+        __device__ T operator()(T x, T) const { return a * x; }
+    };
+    template <typename T>
+    struct AxpbyDev
+    {
+        T sa;
+        const T *a;
+        T b;
+        __device__ T operator()(T x, T y) const { return (sa * *a) * x + b * y; }
+    };
+    template <typename T>
+    struct ScaleInvDev
+    {
+        const T *a;
+        __device__ T operator()(T, T y) const { return y / *a; }
+    };
+    template <typename T>
+    struct Scale
+    {
+        T a;
+        __device__ T operator()(T, T y) const { return y * a; }
+    };
+    template <typename T>
+    struct Const
+    {
+        T a;
+        __device__ T operator()(T, T) const { return a; }
+    };
+    template <typename T>
+    struct Ident
+    {
+        __device__ T operator()(T x, T) const { return x; }
+    };
+    struct Recip
+    {
+        __device__ double operator()(double, double y) const { return 1.0 / y; }
+    };
+
+    // ---------------- reductions
+    template <typename T>
+    __device__ inline T block_sum(T v)
+    {
+        __shared__ T part[BLOCK / WAVE];
+        v = wave_sum(v);
+        const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
+        if (lane == 0)
+            part[w] = v;
+        __syncthreads();
+        T s = T(0);
+        if (threadIdx.x == 0)
+        {
+#pragma unroll
+            for (int i = 0; i < BLOCK / WAVE; ++i)
+                s += part[i];
+        }
+        return s; // valid in thread 0
+    }
+
+    // MODE 0: sum x*y   1: sum (x-y)^2
+    template <typename T, int MODE>
+    __global__ void __launch_bounds__(BLOCK) reduce_stage1(int n, const T *__restrict__ x, const T *__restrict__ y, T *__restrict__ partial,
+                                                           int vectorised)
+    {
+        using V = typename Pack<T>::type;
+        constexpr int N = Pack<T>::N;
+        const int tid = blockIdx.x * BLOCK + threadIdx.x;
+        const int stride = gridDim.x * BLOCK;
+        T acc = T(0);
+        int done = 0;
+        if (vectorised)
+        {
+            const int nv = n / N;
+            for (int i = tid; i < nv; i += stride)
+            {
+                const V xv = reinterpret_cast<const V *>(x)[i];
+                const V yv = reinterpret_cast<const V *>(y)[i];
+                const T *xe = reinterpret_cast<const T *>(&xv);
+                const T *ye = reinterpret_cast<const T *>(&yv);
+#pragma unroll
+                for (int c = 0; c < N; ++c)
+                {
+                    if (MODE == 0)
+                        acc += xe[c] * ye[c];
+                    else
+                    {
+                        const T d = xe[c] - ye[c];
+                        acc += d * d;
+                    }
+                }
+            }
+            done = nv * N;
+        }
+        for (int i = done + tid; i < n; i += stride)
+        {
+            if (MODE == 0)
+                acc += x[i] * y[i];
+            else
+            {
+                const T d = x[i] - y[i];
+                acc += d * d;
+            }
+        }
+        const T s = block_sum(acc);
+        if (threadIdx.x == 0)
+            partial[blockIdx.x] = s;
+    }
+
+    template <typename T, bool SQRT>
+    __global__ void __launch_bounds__(BLOCK) reduce_stage2(int n_partial, const T *__restrict__ partial, T *__restrict__ result)
+    {
+        T acc = T(0);
+        for (int i = threadIdx.x; i < n_partial; i += BLOCK)
+            acc += partial[i];
+        const T s = block_sum(acc);
+        if (threadIdx.x == 0)
+            *result = SQRT ? sqrt(s) : s;
+    }
+
+    template <typename T, int MODE, bool SQRT>
+    int launch_reduce(int n, const T *x, const T *y, T *result, void *ws, void *stream)
+    {
+        T *partial = static_cast<T *>(ws);
+        int g = stream_grid(n, BLOCK, 4 * Pack<T>::N);
+        if (g > MAX_PARTIALS)
+            g = MAX_PARTIALS;
+        const int vec = aligned16(x) && aligned16(y);
+        hipLaunchKernelGGL((reduce_stage1<T, MODE>), dim3(g), dim3(BLOCK), 0, as_stream(stream), n, x, y, partial, vec);
+        hipLaunchKernelGGL((reduce_stage2<T, SQRT>), dim3(1), dim3(BLOCK), 0, as_stream(stream), g, partial, result);
+        return launch_status();
+    }
+
+    // ---------------- indexed maps
+    __global__ void __launch_bounds__(BLOCK) gather_kernel(int n, const int *__restrict__ proj, const double *__restrict__ x, double *__restrict__ y)
+    {
+        for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK)
+            y[i] = x[proj[i]];
+    }
+
+    __global__ void __launch_bounds__(BLOCK) scatter_add_kernel(int n, const int *__restrict__ proj, const double *__restrict__ x, double *__restrict__ y)
+    {
+        // proj is injective (FaceSpace dof -> distinct H1 dof), so a plain read-modify-write is race free
+        for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK)
+            y[proj[i]] += x[i];
+    }
+
+    __global__ void __launch_bounds__(BLOCK) zero_indexed_kernel(int n, const int *__restrict__ proj, double *__restrict__ x)
+    {
+        for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK)
+            x[proj[i]] = 0.0;
+    }
+
+    __global__ void __launch_bounds__(BLOCK) diag_scale_kernel(int n, int accumulate, double c, const double *__restrict__ p, const double *x, double *y)
+    {
+        // x may alias y (DiagInvMassMatrix is applied in place by the DDH example)
+        for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK)
+        {
+            const double v = c * p[i] * x[i];
+            y[i] = accumulate ? y[i] + v : v;
+        }
+    }
+} // namespace
+
+extern "C"
+{
+    size_t cuddh_hip_reduce_ws_bytes(void) { return MAX_PARTIALS * sizeof(double); }
+
+    int cuddh_hip_axpby_f64(int n, double a, const double *x, double b, double *y, void *s)
+    {
+        if (b == 0.0)
+            return launch_map<double, true, false>(n, x, y, Ax<double>{a}, s);
+        return launch_map<double, true, true>(n, x, y, Axpby<double>{a, b}, s);
+    }
+    int cuddh_hip_axpby_f32(int n, float a, const float *x, float b, float *y, void *s)
+    {
+        if (b == 0.0f)
+            return launch_map<float, true, false>(n, x, y, Ax<float>{a}, s);
+        return launch_map<float, true, true>(n, x, y, Axpby<float>{a, b}, s);
+    }
+    int cuddh_hip_axpby_dev_f64(int n, double sa, const double *a, const double *x, double b, double *y, void *s)
+    {
+        return launch_map<double, true, true>(n, x, y, AxpbyDev<double>{sa, a, b}, s);
+    }
+    int cuddh_hip_axpby_dev_f32(int n, float sa, const float *a, const float *x, float b, float *y, void *s)
+    {
+        return launch_map<float, true, true>(n, x, y, AxpbyDev<float>{sa, a, b}, s);
+    }
+    int cuddh_hip_scal_inv_dev_f64(int n, const double *a, double *x, void *s)
+    {
+        return launch_map<double, false, true>(n, static_cast<const double *>(nullptr), x, ScaleInvDev<double>{a}, s);
+    }
+    int cuddh_hip_scal_inv_dev_f32(int n, const float *a, float *x, void *s)
+    {
+        return launch_map<float, false, true>(n, static_cast<const float *>(nullptr), x, ScaleInvDev<float>{a}, s);
+    }
+
+    int cuddh_hip_dot_f64(int n, const double *x, const double *y, double *r, void *ws, void *s) { return launch_reduce<double, 0, false>(n, x, y, r, ws, s); }
+    int cuddh_hip_dot_f32(int n, const float *x, const float *y, float *r, void *ws, void *s) { return launch_reduce<float, 0, false>(n, x, y, r, ws, s); }
+    int cuddh_hip_nrm2_f64(int n, const double *x, double *r, void *ws, void *s) { return launch_reduce<double, 0, true>(n, x, x, r, ws, s); }
+    int cuddh_hip_nrm2_f32(int n, const float *x, float *r, void *ws, void *s) { return launch_reduce<float, 0, true>(n, x, x, r, ws, s); }
+    int cuddh_hip_sqdist_f64(int n, const double *x, const double *y, double *r, void *ws, void *s) { return launch_reduce<double, 1, false>(n, x, y, r, ws, s); }
+    int cuddh_hip_sqdist_f32(int n, const float *x, const float *y, float *r, void *ws, void *s) { return launch_reduce<float, 1, false>(n, x, y, r, ws, s); }
+
+    int cuddh_hip_copy_f64(int n, const double *x, double *y, void *s) { return launch_map<double, true, false>(n, x, y, Ident<double>{}, s); }
+    int cuddh_hip_copy_f32(int n, const float *x, float *y, void *s) { return launch_map<float, true, false>(n, x, y, Ident<float>{}, s); }
+    int cuddh_hip_copy_i32(int n, const int *x, int *y, void *s) { return launch_map<int, true, false>(n, x, y, Ident<int>{}, s); }
+
+    int cuddh_hip_scal_f64(int n, double a, double *x, void *s) { return launch_map<double, false, true>(n, static_cast<const double *>(nullptr), x, Scale<double>{a}, s); }
+    int cuddh_hip_scal_f32(int n, float a, float *x, void *s) { return launch_map<float, false, true>(n, static_cast<const float *>(nullptr), x, Scale<float>{a}, s); }
+
+    int cuddh_hip_fill_f64(int n, double a, double *x, void *s) { return launch_map<double, false, false>(n, static_cast<const double *>(nullptr), x, Const<double>{a}, s); }
+    int cuddh_hip_fill_f32(int n, float a, float *x, void *s) { return launch_map<float, false, false>(n, static_cast<const float *>(nullptr), x, Const<float>{a}, s); }
+    int cuddh_hip_fill_i32(int n, int a, int *x, void *s) { return launch_map<int, false, false>(n, static_cast<const int *>(nullptr), x, Const<int>{a}, s); }
+
+    int cuddh_hip_reciprocal_f64(int n, double *x, void *s) { return launch_map<double, false, true>(n, static_cast<const double *>(nullptr), x, Recip{}, s); }
+
+    int cuddh_hip_diag_scale_f64(int n, int accumulate, double c, const double *p, const double *x, double *y, void *s)
+    {
+        if (n <= 0)
+            return 0;
+        hipLaunchKernelGGL(diag_scale_kernel, dim3(stream_grid(n, BLOCK)), dim3(BLOCK), 0, as_stream(s), n, accumulate, c, p, x, y);
+        return launch_status();
+    }
+
+    int cuddh_hip_gather_f64(int n, const int *proj, const double *x, double *y, void *s)
+    {
+        if (n <= 0)
+            return 0;
+        hipLaunchKernelGGL(gather_kernel, dim3(stream_grid(n, BLOCK)), dim3(BLOCK), 0, as_stream(s), n, proj, x, y);
+        return launch_status();
+    }
+    int cuddh_hip_scatter_add_f64(int n, const int *proj, const double *x, double *y, void *s)
+    {
+        if (n <= 0)
+            return 0;
+        hipLaunchKernelGGL(scatter_add_kernel, dim3(stream_grid(n, BLOCK)), dim3(BLOCK), 0, as_stream(s), n, proj, x, y);
+        return launch_status();
+    }
+    int cuddh_hip_zero_indexed_f64(int n, const int *proj, double *x, void *s)
+    {
+        if (n <= 0)
+            return 0;
+        hipLaunchKernelGGL(zero_indexed_kernel, dim3(stream_grid(n, BLOCK)), dim3(BLOCK), 0, as_stream(s), n, proj, x);
+        return launch_status();
+    }
+}

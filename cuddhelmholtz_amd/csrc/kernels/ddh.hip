@@ -1,0 +1,689 @@
+// DDH local solves (WaveHoltz time stepping of every subdomain) for gfx950.
+//
+// What is computed is the algorithm of reference source/DDH.cpp:111-321; how it
+// is computed is different:
+//   * the stiffness assembly is an owner gather in a fixed order, not float
+//     atomics into LDS (source/DDH.cpp:108), so results are bitwise reproducible;
+//   * `ddh_wave_kernel` (n_basis == 4, 4x4 elements) runs one subdomain per
+//     WAVEFRONT with the whole state in registers: lane = (element, xi-node),
+//     each lane owns the four eta-nodes of its column.  eta-direction
+//     contractions are in-lane FMAs with scalar-register coefficients,
+//     xi-direction contractions read the other three lanes of the quad through
+//     DPP quad_perm operands, element-to-element assembly uses DPP row shifts
+//     (xi neighbours) and one ds_bpermute pair (eta neighbours).  No LDS
+//     storage, no barriers, 25,600 time steps per launch;
+//   * `ddh_block_kernel` (any n_basis <= 10) runs one subdomain per workgroup
+//     with the field staged in LDS, 3 barriers per stiffness sweep.
+#include <algorithm>
+
+#include "common.hpp"
+
+using namespace cuddh_k;
+
+struct cuddh_ddh_plan
+{
+    cuddh_ddh_desc d;
+    int is_f64;
+    int kernel; // 1 block, 2 wave
+    int nodes;  // nb*nb*nel1d*nel1d
+};
+
+namespace
+{
+    constexpr int WH_ITERS = 5; // WaveHoltz iterations (source/DDH.cpp:136)
+
+    template <typename Real>
+    struct DdhArgs
+    {
+        int g_ndof, n_lambda, nt, mx_dof, mx_fdof, nodes, dom_begin, dom_end;
+        Real omega, dt;
+        const int *s_dof, *s_fdof, *B, *gI, *sI;
+        const Real *G, *m, *gmi, *a, *H;
+        const double *x;
+        double *y;
+        const Real *lambda;
+        Real *update;
+    };
+
+    // ---------------------------------------------------------------- DPP helpers
+    template <int CTRL>
+    __device__ inline float dpp_read(float v)
+    {
+        return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+    }
+
+    template <int CTRL>
+    __device__ inline double dpp_read(double v)
+    {
+        const long long bits = __double_as_longlong(v);
+        const int lo = __builtin_amdgcn_update_dpp(0, static_cast<int>(bits), CTRL, 0xf, 0xf, true);
+        const int hi = __builtin_amdgcn_update_dpp(0, static_cast<int>(bits >> 32), CTRL, 0xf, 0xf, true);
+        return __longlong_as_double((static_cast<long long>(hi) << 32) | static_cast<unsigned int>(lo));
+    }
+
+    constexpr int QUAD_BCAST(int i) { return i * 0x55; } // quad_perm:[i,i,i,i]
+    constexpr int ROW_SHL1 = 0x101;                      // lane j reads lane j+1 of its 16-lane row
+    constexpr int ROW_SHR1 = 0x111;                      // lane j reads lane j-1
+
+    // ---------------------------------------------------------------- wavefront-per-subdomain kernel (NB = 4, 4x4 elements)
+    template <typename Real>
+    __device__ inline void wave_stiffness(const Real (&w)[4], Real (&z)[4], const Real (&gx)[4], const Real (&gy)[4], const Real (&gz)[4],
+                                          const Real (&Dk)[4], const Real (&DTk)[4], const Real *__restrict__ Dm, Real mR, Real mL,
+                                          Real mU, Real mD, int lane)
+    {
+        Real ux[4], uy[4];
+        // eta derivative: in-lane, uniform coefficients D(l, i)
+#pragma unroll
+        for (int l = 0; l < 4; ++l)
+        {
+            Real s = Dm[l] * w[0];
+#pragma unroll
+            for (int i = 1; i < 4; ++i)
+                s += Dm[l + 4 * i] * w[i];
+            uy[l] = s;
+        }
+        // xi derivative: u(i, l) sits in lane i of my quad
+#pragma unroll
+        for (int l = 0; l < 4; ++l)
+        {
+            Real s = Dk[0] * dpp_read<QUAD_BCAST(0)>(w[l]);
+            s += Dk[1] * dpp_read<QUAD_BCAST(1)>(w[l]);
+            s += Dk[2] * dpp_read<QUAD_BCAST(2)>(w[l]);
+            s += Dk[3] * dpp_read<QUAD_BCAST(3)>(w[l]);
+            ux[l] = s;
+        }
+        Real f1[4], f2[4];
+#pragma unroll
+        for (int l = 0; l < 4; ++l)
+        {
+            f1[l] = gx[l] * ux[l] + gy[l] * uy[l];
+            f2[l] = gy[l] * ux[l] + gz[l] * uy[l];
+        }
+        // test functions: sum_i D(i,k) f1(i,l)  +  sum_i D(i,l) f2(k,i)
+#pragma unroll
+        for (int l = 0; l < 4; ++l)
+        {
+            Real s = DTk[0] * dpp_read<QUAD_BCAST(0)>(f1[l]);
+            s += DTk[1] * dpp_read<QUAD_BCAST(1)>(f1[l]);
+            s += DTk[2] * dpp_read<QUAD_BCAST(2)>(f1[l]);
+            s += DTk[3] * dpp_read<QUAD_BCAST(3)>(f1[l]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                s += Dm[i + 4 * l] * f2[i];
+            z[l] = s;
+        }
+        // assembly across elements.  xi neighbours: my k==3 column meets the k==0 column of lane+1 (and vice versa)
+#pragma unroll
+        for (int l = 0; l < 4; ++l)
+        {
+            const Real from_right = dpp_read<ROW_SHL1>(z[l]);
+            const Real from_left = dpp_read<ROW_SHR1>(z[l]);
+            z[l] = (z[l] + mR * from_right) + mL * from_left;
+        }
+        // eta neighbours: my l==3 node meets the l==0 node of lane+16 (and vice versa)
+        {
+            const Real top = z[3], bottom = z[0];
+            const Real from_above = __shfl(bottom, (lane + 16) & 63, 64);
+            const Real from_below = __shfl(top, (lane + 48) & 63, 64);
+            z[3] = top + mU * from_above;
+            z[0] = bottom + mD * from_below;
+        }
+    }
+
+    template <typename Real>
+    __global__ void __launch_bounds__(256) ddh_wave_kernel(DdhArgs<Real> A, const Real *__restrict__ Dmat, const Real *__restrict__ filt,
+                                                          const Real *__restrict__ cs, const Real *__restrict__ sn)
+    {
+        const int lane = threadIdx.x & 63;
+        const int s = A.dom_begin + blockIdx.x * 4 + (threadIdx.x >> 6);
+        if (s >= A.dom_end)
+            return; // wave-uniform: the kernel has no barriers
+
+        const int k = lane & 3, el = lane >> 2, ex = el & 3, ey = el >> 2;
+        const int fdof = A.s_fdof[s];
+        const int *sI = A.sI + 256 * (size_t)s;
+        const size_t dbase = (size_t)A.mx_dof * s, fbase = (size_t)A.mx_fdof * s;
+
+        Real gx[4], gy[4], gz[4], invm[4], Hi[4], F[4], Gf[4];
+        Real p[4], q[4], u[4], v[4];
+#pragma unroll
+        for (int l = 0; l < 4; ++l)
+        {
+            const int node = k + 4 * (l + 4 * el);
+            const int d = sI[node];
+            const Real *g = A.G + 3 * ((size_t)node + 256 * (size_t)s);
+            gx[l] = g[0];
+            gy[l] = g[1];
+            gz[l] = g[2];
+            const Real ai = A.a[dbase + d], mi = A.m[dbase + d];
+            invm[l] = Real(1) / (ai * ai * mi);
+            Real f = 0, gg = 0, h = 0;
+            if (A.x)
+            {
+                const int gidx = A.gI[dbase + d];
+                f = static_cast<Real>(A.x[gidx]);
+                gg = static_cast<Real>(A.x[A.g_ndof + gidx]);
+            }
+            if (d < fdof)
+            {
+                h = A.H[fbase + d];
+                if (A.lambda)
+                {
+                    const int slot = A.B[d + (size_t)A.mx_fdof * (0 + 2 * (size_t)s)];
+                    if (slot >= 0)
+                    {
+                        f += h * A.lambda[slot];
+                        gg += h * A.lambda[A.n_lambda + slot];
+                    }
+                }
+                h *= ai;
+            }
+            F[l] = f;
+            Gf[l] = gg;
+            Hi[l] = h;
+            p[l] = q[l] = u[l] = v[l] = 0;
+        }
+
+        Real Dk[4], DTk[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+        {
+            Dk[i] = Dmat[k + 4 * i];  // D(k, i)
+            DTk[i] = Dmat[i + 4 * k]; // D(i, k)
+        }
+        const Real mR = (k == 3 && ex < 3) ? Real(1) : Real(0);
+        const Real mL = (k == 0 && ex > 0) ? Real(1) : Real(0);
+        const Real mU = (ey < 3) ? Real(1) : Real(0);
+        const Real mD = (ey > 0) ? Real(1) : Real(0);
+
+        const Real dt = A.dt, half_dt = Real(0.5) * A.dt;
+        const int nt = A.nt;
+
+        for (int whit = 0; whit < WH_ITERS; ++whit)
+        {
+            {
+                const Real k0 = filt[0];
+#pragma unroll
+                for (int l = 0; l < 4; ++l)
+                {
+                    p[l] = u[l];
+                    q[l] = v[l];
+                    u[l] *= k0;
+                    v[l] *= k0;
+                }
+            }
+            for (int it = 1; it <= nt; ++it)
+            {
+                const Real c0 = cs[2 * it - 2], s0 = sn[2 * it - 2];
+                const Real c1 = cs[2 * it - 1], s1 = sn[2 * it - 1];
+                const Real kw = filt[it];
+                Real z[4], ph[4], qh[4];
+
+                wave_stiffness(p, z, gx, gy, gz, Dk, DTk, Dmat, mR, mL, mU, mD, lane);
+#pragma unroll
+                for (int l = 0; l < 4; ++l)
+                {
+                    const Real dq = ((z[l] - Hi[l] * q[l]) + c0 * F[l] + s0 * Gf[l]) * invm[l];
+                    ph[l] = p[l] - half_dt * q[l];
+                    qh[l] = q[l] + half_dt * dq;
+                    p[l] -= dt * qh[l];
+                }
+                wave_stiffness(ph, z, gx, gy, gz, Dk, DTk, Dmat, mR, mL, mU, mD, lane);
+#pragma unroll
+                for (int l = 0; l < 4; ++l)
+                {
+                    const Real dq = ((z[l] - Hi[l] * qh[l]) + c1 * F[l] + s1 * Gf[l]) * invm[l];
+                    q[l] += dt * dq;
+                    u[l] += kw * p[l];
+                    v[l] += kw * q[l];
+                }
+            }
+        }
+
+        const Real rw = Real(1) / A.omega;
+#pragma unroll
+        for (int l = 0; l < 4; ++l)
+        {
+            v[l] *= rw;
+            // every shared node is held by 2 or 4 (lane, l) pairs with identical values: the copy with
+            // the smallest element-node index writes
+            const bool owner = !(k == 0 && ex > 0) && !(l == 0 && ey > 0);
+            if (!owner)
+                continue;
+            const int d = sI[k + 4 * (l + 4 * el)];
+            if (A.y)
+            {
+                const int gidx = A.gI[dbase + d];
+                const Real M = A.m[dbase + d] * A.gmi[dbase + d];
+                atomic_add(A.y + gidx, static_cast<double>(M * u[l]));
+                atomic_add(A.y + A.g_ndof + gidx, static_cast<double>(M * v[l]));
+            }
+            if (A.update && d < fdof)
+            {
+                const int wslot = A.B[d + (size_t)A.mx_fdof * (1 + 2 * (size_t)s)];
+                if (wslot >= 0)
+                {
+                    Real lam = 0, mu = 0;
+                    if (A.lambda)
+                    {
+                        const int rslot = A.B[d + (size_t)A.mx_fdof * (0 + 2 * (size_t)s)];
+                        if (rslot >= 0)
+                        {
+                            lam = A.lambda[rslot];
+                            mu = A.lambda[A.n_lambda + rslot];
+                        }
+                    }
+                    const Real S = Real(2) * A.a[dbase + d] * A.omega;
+                    A.update[wslot] = -lam - S * v[l];
+                    A.update[A.n_lambda + wslot] = -mu + S * u[l];
+                }
+            }
+        }
+    }
+
+    // structure check for the wave kernel: 169 dofs, xi/eta neighbours share exactly the expected nodes
+    __global__ void __launch_bounds__(256) ddh_wave_check_kernel(int n_domains, const int *__restrict__ s_dof, const int *__restrict__ sI,
+                                                                 int *__restrict__ bad)
+    {
+        const int s = blockIdx.x, tid = threadIdx.x;
+        if (s >= n_domains)
+            return;
+        const int k = tid & 3, l = (tid >> 2) & 3, el = tid >> 4, ex = el & 3, ey = el >> 2;
+        const int *I = sI + 256 * (size_t)s;
+        bool ok = I[tid] >= 0 && I[tid] < 169;
+        if (tid == 0)
+            ok = ok && s_dof[s] == 169;
+        if (k == 3 && ex < 3)
+            ok = ok && I[tid] == I[0 + 4 * (l + 4 * (el + 1))];
+        if (l == 3 && ey < 3)
+            ok = ok && I[tid] == I[k + 4 * (0 + 4 * (el + 4))];
+        if (!ok)
+            atomicExch(bad, 1);
+    }
+
+    // ---------------------------------------------------------------- workgroup-per-subdomain kernel (generic)
+    template <typename Real, int NB>
+    __global__ void __launch_bounds__(256) ddh_block_kernel(DdhArgs<Real> A, const Real *__restrict__ Dmat, const Real *__restrict__ filt,
+                                                           const Real *__restrict__ cs, const Real *__restrict__ sn)
+    {
+        const int T = A.nodes; // == blockDim.x
+        const int tid = threadIdx.x;
+        const int s = A.dom_begin + blockIdx.x;
+
+        extern __shared__ double lds_raw[];
+        Real *s_p = reinterpret_cast<Real *>(lds_raw); // [T] field, indexed by subdomain dof
+        Real *s_f1 = s_p + T;                           // [T] fluxes, indexed by element node
+        Real *s_f2 = s_f1 + T;
+        Real *s_su = s_f2 + T;                          // [T] element contributions
+        int *s_cnt = reinterpret_cast<int *>(s_su + T); // [T]
+        int *s_lst = s_cnt + T;                         // [T][4]
+
+        const int ndof = A.s_dof[s], fdof = A.s_fdof[s];
+        const int k = tid % NB, l = (tid / NB) % NB, el = tid / (NB * NB);
+        const int *sI = A.sI + (size_t)T * s;
+        const int mydof = sI[tid];
+        const bool active = mydof >= 0;
+
+        int row[NB], col[NB];
+        Real Dk[NB], Dl[NB], DTk[NB], DTl[NB];
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+        {
+            row[i] = active ? sI[i + NB * (l + NB * el)] : 0; // dof of node (i, l)
+            col[i] = active ? sI[k + NB * (i + NB * el)] : 0; // dof of node (k, i)
+            Dk[i] = Dmat[k + NB * i];
+            Dl[i] = Dmat[l + NB * i];
+            DTk[i] = Dmat[i + NB * k];
+            DTl[i] = Dmat[i + NB * l];
+        }
+        const Real *g = A.G + 3 * ((size_t)tid + (size_t)T * s);
+        const Real g0 = active ? g[0] : Real(0), g1 = active ? g[1] : Real(0), g2 = active ? g[2] : Real(0);
+
+        // who contributes to dof `tid`: element nodes in increasing order (fixed summation order)
+        s_cnt[tid] = 0;
+        __syncthreads();
+        if (active)
+        {
+            const int slot = atomicAdd(&s_cnt[mydof], 1);
+            if (slot < 4)
+                s_lst[4 * mydof + slot] = tid;
+        }
+        __syncthreads();
+        int nc = 0, c[4] = {0, 0, 0, 0};
+        if (tid < ndof)
+        {
+            nc = s_cnt[tid];
+            if (nc > 4)
+                __builtin_trap(); // more than four elements meet at a node: not a structured subdomain
+            for (int j = 0; j < nc; ++j)
+                c[j] = s_lst[4 * tid + j];
+            for (int a = 1; a < nc; ++a) // insertion sort of at most 4 entries
+                for (int b = a; b > 0 && c[b - 1] > c[b]; --b)
+                {
+                    const int t = c[b];
+                    c[b] = c[b - 1];
+                    c[b - 1] = t;
+                }
+        }
+
+        // per-dof data
+        int g_idx = -1;
+        Real ai = 0, mi = 0, inv_mi = 0, Hi = 0, F = 0, G = 0, lam = 0, mu = 0;
+        Real u = 0, v = 0, p = 0, q = 0;
+        const size_t dbase = (size_t)A.mx_dof * s, fbase = (size_t)A.mx_fdof * s;
+        if (tid < ndof)
+        {
+            g_idx = A.gI[dbase + tid];
+            ai = A.a[dbase + tid];
+            mi = A.m[dbase + tid];
+            inv_mi = Real(1) / (ai * ai * mi);
+            if (A.x)
+            {
+                F = static_cast<Real>(A.x[g_idx]);
+                G = static_cast<Real>(A.x[A.g_ndof + g_idx]);
+            }
+        }
+        if (tid < fdof)
+        {
+            Hi = A.H[fbase + tid];
+            if (A.lambda)
+            {
+                const int slot = A.B[tid + (size_t)A.mx_fdof * (0 + 2 * (size_t)s)];
+                if (slot >= 0)
+                {
+                    lam = A.lambda[slot];
+                    mu = A.lambda[A.n_lambda + slot];
+                    F += Hi * lam;
+                    G += Hi * mu;
+                }
+            }
+            Hi *= ai;
+        }
+
+        // one stiffness sweep: field in s_p (already published), returns (S field)[tid] for tid < ndof
+        auto sweep = [&]() -> Real
+        {
+            Real Ux = 0, Uy = 0;
+#pragma unroll
+            for (int i = 0; i < NB; ++i)
+            {
+                Ux += Dk[i] * s_p[row[i]];
+                Uy += Dl[i] * s_p[col[i]];
+            }
+            s_f1[tid] = g0 * Ux + g1 * Uy;
+            s_f2[tid] = g1 * Ux + g2 * Uy;
+            __syncthreads();
+            Real Su = 0;
+#pragma unroll
+            for (int i = 0; i < NB; ++i)
+            {
+                Su += DTk[i] * s_f1[i + NB * (l + NB * el)];
+                Su += DTl[i] * s_f2[k + NB * (i + NB * el)];
+            }
+            s_su[tid] = Su;
+            __syncthreads();
+            Real z = 0;
+            for (int j = 0; j < nc; ++j)
+                z += s_su[c[j]];
+            return z;
+        };
+
+        const Real dt = A.dt, half_dt = Real(0.5) * A.dt;
+        const int nt = A.nt;
+        for (int whit = 0; whit < WH_ITERS; ++whit)
+        {
+            const Real k0 = filt[0];
+            p = u;
+            q = v;
+            u *= k0;
+            v *= k0;
+            for (int it = 1; it <= nt; ++it)
+            {
+                s_p[tid] = p;
+                __syncthreads();
+                Real z = sweep() - Hi * q;
+                Real dq = (z + cs[2 * it - 2] * F + sn[2 * it - 2] * G) * inv_mi;
+                const Real ph = p - half_dt * q;
+                const Real qh = q + half_dt * dq;
+                p -= dt * qh;
+
+                s_p[tid] = ph;
+                __syncthreads();
+                z = sweep() - Hi * qh;
+                dq = (z + cs[2 * it - 1] * F + sn[2 * it - 1] * G) * inv_mi;
+                q += dt * dq;
+
+                const Real kw = filt[it];
+                u += kw * p;
+                v += kw * q;
+            }
+        }
+
+        v *= Real(1) / A.omega;
+
+        if (A.y && tid < ndof)
+        {
+            const Real M = mi * A.gmi[dbase + tid];
+            atomic_add(A.y + g_idx, static_cast<double>(M * u));
+            atomic_add(A.y + A.g_ndof + g_idx, static_cast<double>(M * v));
+        }
+        if (A.update && tid < fdof)
+        {
+            const int wslot = A.B[tid + (size_t)A.mx_fdof * (1 + 2 * (size_t)s)];
+            if (wslot >= 0)
+            {
+                const Real S = Real(2) * ai * A.omega;
+                A.update[wslot] = -lam - S * v;
+                A.update[A.n_lambda + wslot] = -mu + S * u;
+            }
+        }
+    }
+
+    // ---------------------------------------------------------------- geometric factors (K13)
+    template <typename Real>
+    __global__ void __launch_bounds__(256) ddh_geom_kernel(long long total, int nodes, int nb, int mx_elems, const int *__restrict__ n_elems,
+                                                          const int *__restrict__ elems, const double *__restrict__ w,
+                                                          const double *__restrict__ J, Real *__restrict__ G)
+    {
+        for (long long t = blockIdx.x * 256LL + threadIdx.x; t < total; t += gridDim.x * 256LL)
+        {
+            const int s = static_cast<int>(t / nodes), node = static_cast<int>(t % nodes);
+            const int i = node % nb, j = (node / nb) % nb, el = node / (nb * nb);
+            Real *g = G + 3 * t;
+            if (el >= n_elems[s])
+            {
+                g[0] = g[1] = g[2] = 0;
+                continue;
+            }
+            const int g_el = elems[el + (size_t)mx_elems * s];
+            const double *Jp = J + 4 * ((size_t)i + nb * ((size_t)j + nb * (size_t)g_el));
+            const double W = w[i] * w[j];
+            const double x_xi = Jp[0], y_xi = Jp[1], x_eta = Jp[2], y_eta = Jp[3];
+            const double det = x_xi * y_eta - x_eta * y_xi;
+            g[0] = static_cast<Real>(W * (y_eta * y_eta + x_eta * x_eta) / det);
+            g[1] = static_cast<Real>(-W * (y_xi * y_eta + x_xi * x_eta) / det);
+            g[2] = static_cast<Real>(W * (y_xi * y_xi + x_xi * x_xi) / det);
+        }
+    }
+
+    template <typename Real>
+    int geom_setup(int n_domains, int mx_elems, int nb, const int *n_elems, const int *elems, const double *w, const double *J, Real *G,
+                   void *stream)
+    {
+        const int nodes = nb * nb * mx_elems;
+        const long long total = (long long)nodes * n_domains;
+        if (total <= 0)
+            return 0;
+        hipLaunchKernelGGL((ddh_geom_kernel<Real>), dim3(stream_grid(total, 256)), dim3(256), 0, as_stream(stream), total, nodes, nb,
+                           mx_elems, n_elems, elems, w, J, G);
+        return launch_status();
+    }
+
+    template <typename Real, int NB>
+    void launch_block(const DdhArgs<Real> &A, const cuddh_ddh_desc &d, int n_local, hipStream_t st)
+    {
+        const int T = A.nodes;
+        const size_t lds = (size_t)T * (4 * sizeof(Real) + 5 * sizeof(int));
+        hipLaunchKernelGGL((ddh_block_kernel<Real, NB>), dim3(n_local), dim3(T), lds, st, A, static_cast<const Real *>(d.D),
+                           static_cast<const Real *>(d.wh_filter), static_cast<const Real *>(d.cs), static_cast<const Real *>(d.sn));
+    }
+
+    template <typename Real>
+    int apply(const cuddh_ddh_plan *plan, int dom_begin, int dom_end, const double *x, double *y, int zero_y, const Real *lambda,
+              Real *update, void *stream)
+    {
+        if (!plan || plan->is_f64 != (sizeof(Real) == 8 ? 1 : 0))
+            return static_cast<int>(hipErrorInvalidValue);
+        const cuddh_ddh_desc &d = plan->d;
+        if (dom_begin < 0 || dom_end > d.n_domains || dom_begin > dom_end)
+            return static_cast<int>(hipErrorInvalidValue);
+        hipStream_t st = as_stream(stream);
+        if (y && zero_y)
+        {
+            hipError_t e = hipMemsetAsync(y, 0, (size_t)2 * d.g_ndof * sizeof(double), st);
+            if (e != hipSuccess)
+                return static_cast<int>(e);
+        }
+        const int n_local = dom_end - dom_begin;
+        if (n_local == 0)
+            return 0;
+
+        DdhArgs<Real> A;
+        A.g_ndof = d.g_ndof;
+        A.n_lambda = d.n_lambda;
+        A.nt = d.nt;
+        A.mx_dof = d.mx_dof;
+        A.mx_fdof = d.mx_fdof;
+        A.nodes = plan->nodes;
+        A.dom_begin = dom_begin;
+        A.dom_end = dom_end;
+        A.omega = static_cast<Real>(d.omega);
+        A.dt = static_cast<Real>(d.dt);
+        A.s_dof = d.s_dof;
+        A.s_fdof = d.s_fdof;
+        A.B = d.B;
+        A.gI = d.gI;
+        A.sI = d.sI;
+        A.G = static_cast<const Real *>(d.G);
+        A.m = static_cast<const Real *>(d.m);
+        A.gmi = static_cast<const Real *>(d.gmi);
+        A.a = static_cast<const Real *>(d.a);
+        A.H = static_cast<const Real *>(d.H);
+        A.x = x;
+        A.y = y;
+        A.lambda = lambda;
+        A.update = update;
+
+        if (plan->kernel == 2)
+        {
+            hipLaunchKernelGGL((ddh_wave_kernel<Real>), dim3((n_local + 3) / 4), dim3(256), 0, st, A, static_cast<const Real *>(d.D),
+                               static_cast<const Real *>(d.wh_filter), static_cast<const Real *>(d.cs), static_cast<const Real *>(d.sn));
+            return launch_status();
+        }
+
+        switch (d.nb)
+        {
+        case 2: launch_block<Real, 2>(A, d, n_local, st); break;
+        case 3: launch_block<Real, 3>(A, d, n_local, st); break;
+        case 4: launch_block<Real, 4>(A, d, n_local, st); break;
+        case 5: launch_block<Real, 5>(A, d, n_local, st); break;
+        case 6: launch_block<Real, 6>(A, d, n_local, st); break;
+        case 7: launch_block<Real, 7>(A, d, n_local, st); break;
+        case 8: launch_block<Real, 8>(A, d, n_local, st); break;
+        case 9: launch_block<Real, 9>(A, d, n_local, st); break;
+        case 10: launch_block<Real, 10>(A, d, n_local, st); break;
+        default: return static_cast<int>(hipErrorInvalidValue);
+        }
+        return launch_status();
+    }
+} // namespace
+
+extern "C"
+{
+    int cuddh_hip_ddh_geom_setup_f32(int n_domains, int mx_elems, int g_elem, int nb, const int *n_elems, const int *elems,
+                                     const double *w, const double *J, float *G, void *stream)
+    {
+        (void)g_elem;
+        return geom_setup<float>(n_domains, mx_elems, nb, n_elems, elems, w, J, G, stream);
+    }
+
+    int cuddh_hip_ddh_geom_setup_f64(int n_domains, int mx_elems, int g_elem, int nb, const int *n_elems, const int *elems,
+                                     const double *w, const double *J, double *G, void *stream)
+    {
+        (void)g_elem;
+        return geom_setup<double>(n_domains, mx_elems, nb, n_elems, elems, w, J, G, stream);
+    }
+
+    int cuddh_hip_ddh_plan_create(cuddh_ddh_plan **out, const cuddh_ddh_desc *desc, int is_f64, int kernel)
+    {
+        *out = nullptr;
+        if (!desc || desc->nb < 2 || desc->nb > 10 || desc->nel1d < 1)
+            return static_cast<int>(hipErrorInvalidValue);
+        const int nodes = desc->nb * desc->nb * desc->nel1d * desc->nel1d;
+        if (nodes > 256)
+            return static_cast<int>(hipErrorInvalidValue);
+
+        cuddh_ddh_plan *p = new cuddh_ddh_plan;
+        p->d = *desc;
+        p->is_f64 = is_f64 ? 1 : 0;
+        p->nodes = nodes;
+        p->kernel = 1;
+
+        const bool wave_shape = (desc->nb == 4 && desc->nel1d == 4);
+        if (kernel == 2 && !wave_shape)
+        {
+            delete p;
+            return static_cast<int>(hipErrorInvalidValue);
+        }
+        if (wave_shape && kernel != 1)
+        {
+            int *flag = nullptr;
+            hipError_t e = hipMalloc(&flag, sizeof(int));
+            if (e == hipSuccess)
+                e = hipMemset(flag, 0, sizeof(int));
+            int bad = 1;
+            if (e == hipSuccess)
+            {
+                hipLaunchKernelGGL(ddh_wave_check_kernel, dim3(desc->n_domains), dim3(256), 0, nullptr, desc->n_domains, desc->s_dof,
+                                   desc->sI, flag);
+                e = hipMemcpy(&bad, flag, sizeof(int), hipMemcpyDeviceToHost);
+            }
+            if (flag)
+                (void)hipFree(flag);
+            if (e != hipSuccess)
+            {
+                delete p;
+                return static_cast<int>(e);
+            }
+            if (!bad)
+                p->kernel = 2;
+            else if (kernel == 2)
+            {
+                delete p;
+                return static_cast<int>(hipErrorInvalidValue);
+            }
+        }
+        *out = p;
+        return 0;
+    }
+
+    int cuddh_hip_ddh_plan_destroy(cuddh_ddh_plan *plan)
+    {
+        delete plan;
+        return 0;
+    }
+
+    int cuddh_hip_ddh_plan_kernel(const cuddh_ddh_plan *plan) { return plan ? plan->kernel : 0; }
+
+    int cuddh_hip_ddh_apply_f32(const cuddh_ddh_plan *plan, int dom_begin, int dom_end, const double *x, double *y, int zero_y,
+                                const float *lambda, float *update, void *stream)
+    {
+        return apply<float>(plan, dom_begin, dom_end, x, y, zero_y, lambda, update, stream);
+    }
+
+    int cuddh_hip_ddh_apply_f64(const cuddh_ddh_plan *plan, int dom_begin, int dom_end, const double *x, double *y, int zero_y,
+                                const double *lambda, double *update, void *stream)
+    {
+        return apply<double>(plan, dom_begin, dom_end, x, y, zero_y, lambda, update, stream);
+    }
+}

@@ -1,0 +1,678 @@
+// Fused complex Helmholtz apply  [u;v] -> [S u - w^2 M u - w H v ; -(S v - w^2 M v + w H u)].
+//
+// Bandwidth design (MI355X): elements are grouped into PATCHES of 32 (Morton
+// order of their centroids: 4x8 blocks on a structured mesh).  One wavefront
+// owns one patch; lane = (element, component): lanes 0-31 apply the operators to
+// u, lanes 32-63 to v of the same 32 elements, so the metric tensors, the mass
+// weights and the index map are fetched once for both components.
+//   * x of the patch's dofs is gathered once into LDS (x_u, x_v); results are
+//     accumulated in LDS (y_u, y_v) in colour phases (elements of one colour share
+//     no dof), i.e. without atomics and in a fixed order;
+//   * each lane runs the whole sum factorisation of its element in registers;
+//     the 1-D interpolation/differentiation matrices are compile-time-indexed
+//     loads from a uniform pointer (scalar registers);
+//   * metric arrays are stored patch-major, structure-of-arrays
+//     [patch][component][point][32 lanes]: every load instruction reads 256
+//     contiguous bytes;
+//   * dofs owned by one patch are stored straight to y; dofs on patch borders go
+//     to per-patch slots that a second small kernel sums in a fixed order.
+// The apply is therefore bitwise reproducible and needs no zero-fill of y.
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "common.hpp"
+
+using namespace cuddh_k;
+
+struct cuddh_helmholtz_plan
+{
+    int ndof = 0, n_elem = 0, nb = 0, nqS = 0, nqM = 0, nqF = 0, n_faces = 0;
+    int n_patches = 0, max_loc = 0, ncol = 0, nfcol = 0, n_shared = 0, n_slots = 0;
+    // per patch
+    int *dof_off = nullptr;   // [n_patches + 1] offsets into dof_list / slot_of
+    int *dof_list = nullptr;  // global dof of every patch-local dof
+    int *slot_of = nullptr;   // -1: the patch owns the dof, else its slot in `part`
+    int *patch_nel = nullptr; // elements in the patch (32 except possibly the last)
+    uint16_t *lidx = nullptr; // [n_patches][nb*nb][32] element node -> patch-local dof
+    uint8_t *colour = nullptr; // [n_patches][32]
+    double *Gp = nullptr;     // [n_patches][3][nqS*nqS][32]
+    double *aMp = nullptr;    // [n_patches][nqM*nqM][32]
+    // faces, grouped by patch
+    int *face_off = nullptr;       // [n_patches + 1]
+    uint16_t *face_lidx = nullptr; // [n_faces_total][nb]
+    int *face_id = nullptr;        // original face index (column of aF)
+    uint8_t *face_col = nullptr;
+    const double *aF = nullptr; // borrowed: (nqF, n_faces)
+    // basis tables
+    double *PS = nullptr, *DS = nullptr, *PM = nullptr, *PF = nullptr;
+    // patch-border dofs
+    int *shared_dof = nullptr, *shared_off = nullptr, *shared_slots = nullptr;
+    double *part = nullptr; // [2][n_slots]
+    size_t bytes_alg = 0, bytes_actual = 0;
+};
+
+namespace
+{
+    constexpr int PE = 32; // elements per patch
+
+    struct HelmArgs
+    {
+        int ndof, max_loc, ncol, nfcol, nqF, n_slots;
+        double omega;
+        const int *dof_off, *dof_list, *slot_of, *patch_nel, *face_off, *face_id;
+        const uint16_t *lidx, *face_lidx;
+        const uint8_t *colour, *face_col;
+        const double *Gp, *aMp, *aF;
+        const double *x;
+        double *y, *part;
+    };
+
+    template <int NB, int NQS, int NQM>
+    __global__ void __launch_bounds__(64, (NB >= 5 ? 2 : 4)) helm_patch_kernel(HelmArgs A, const double *__restrict__ PS, const double *__restrict__ DS,
+                                                           const double *__restrict__ PM, const double *__restrict__ PF)
+    {
+        constexpr int NN = NB * NB;
+        extern __shared__ double lds[];
+        const int patch = blockIdx.x, lane = threadIdx.x;
+        const int comp = lane >> 5, le = lane & 31;
+        const int ML = A.max_loc;
+        double *xs = lds;          // [2][ML]
+        double *ys = lds + 2 * ML; // [2][ML]
+
+        const int off = A.dof_off[patch];
+        const int nloc = A.dof_off[patch + 1] - off;
+        const int *dofs = A.dof_list + off;
+
+        for (int i = lane; i < nloc; i += 64)
+        {
+            const int g = dofs[i];
+            xs[i] = A.x[g];
+            xs[ML + i] = A.x[A.ndof + g];
+            ys[i] = 0.0;
+            ys[ML + i] = 0.0;
+        }
+        __syncthreads();
+
+        // ------------------------------------------------------------ element phase
+        const bool active = le < A.patch_nel[patch];
+        const uint16_t *li = A.lidx + ((size_t)patch * NN) * PE + le;
+        const double *xc = xs + comp * ML;
+
+        double u[NN], out[NN];
+#pragma unroll
+        for (int n = 0; n < NN; ++n)
+        {
+            u[n] = active ? xc[li[n * PE]] : 0.0;
+            out[n] = 0.0;
+        }
+
+        // stiffness: out(k,l) += sum_q [ D(q,k) sum_r P(r,l) F0(q,r) + P(q,k) sum_r D(r,l) F1(q,r) ]
+        {
+            const double *Gp = A.Gp + (size_t)patch * 3 * NQS * NQS * PE + le;
+            // q stays a real loop: one iteration keeps 3*NQS metric loads in flight, which is enough to cover the
+            // HBM latency; unrolling it lets the scheduler hoist every load of the element and exhausts the VGPRs
+#pragma unroll 1
+            for (int q = 0; q < NQS; ++q)
+            {
+                double pu[NB], du[NB], t0[NB], t1[NB];
+#pragma unroll
+                for (int l = 0; l < NB; ++l)
+                {
+                    double a = 0.0, b = 0.0;
+#pragma unroll
+                    for (int k = 0; k < NB; ++k)
+                    {
+                        a += PS[q + NQS * k] * u[k + NB * l];
+                        b += DS[q + NQS * k] * u[k + NB * l];
+                    }
+                    pu[l] = a;
+                    du[l] = b;
+                    t0[l] = 0.0;
+                    t1[l] = 0.0;
+                }
+#pragma unroll
+                for (int r = 0; r < NQS; ++r)
+                {
+                    const int pt = q + NQS * r;
+                    const double ga = Gp[(0 * NQS * NQS + pt) * PE];
+                    const double gb = Gp[(1 * NQS * NQS + pt) * PE];
+                    const double gc = Gp[(2 * NQS * NQS + pt) * PE];
+                    double dx = 0.0, dy = 0.0;
+#pragma unroll
+                    for (int l = 0; l < NB; ++l)
+                    {
+                        dx += PS[r + NQS * l] * du[l];
+                        dy += DS[r + NQS * l] * pu[l];
+                    }
+                    const double f0 = ga * dx + gb * dy;
+                    const double f1 = gb * dx + gc * dy;
+#pragma unroll
+                    for (int l = 0; l < NB; ++l)
+                    {
+                        t0[l] += PS[r + NQS * l] * f0;
+                        t1[l] += DS[r + NQS * l] * f1;
+                    }
+                }
+#pragma unroll
+                for (int l = 0; l < NB; ++l)
+#pragma unroll
+                    for (int k = 0; k < NB; ++k)
+                        out[k + NB * l] += DS[q + NQS * k] * t0[l] + PS[q + NQS * k] * t1[l];
+            }
+        }
+
+        // mass: out(k,l) += -w^2 sum_q P(q,k) sum_r P(r,l) a(q,r) (sum_{k'l'} P(q,k') P(r,l') u(k',l'))
+        {
+            const double *ap = A.aMp + (size_t)patch * NQM * NQM * PE + le;
+            const double w2 = -A.omega * A.omega;
+#pragma unroll 1
+            for (int q = 0; q < NQM; ++q)
+            {
+                double pu[NB], t[NB];
+#pragma unroll
+                for (int l = 0; l < NB; ++l)
+                {
+                    double a = 0.0;
+#pragma unroll
+                    for (int k = 0; k < NB; ++k)
+                        a += PM[q + NQM * k] * u[k + NB * l];
+                    pu[l] = a;
+                    t[l] = 0.0;
+                }
+#pragma unroll
+                for (int r = 0; r < NQM; ++r)
+                {
+                    double val = 0.0;
+#pragma unroll
+                    for (int l = 0; l < NB; ++l)
+                        val += PM[r + NQM * l] * pu[l];
+                    val *= ap[(q + NQM * r) * PE] * w2;
+#pragma unroll
+                    for (int l = 0; l < NB; ++l)
+                        t[l] += PM[r + NQM * l] * val;
+                }
+#pragma unroll
+                for (int l = 0; l < NB; ++l)
+#pragma unroll
+                    for (int k = 0; k < NB; ++k)
+                        out[k + NB * l] += PM[q + NQM * k] * t[l];
+            }
+        }
+
+        // accumulate: elements of one colour touch disjoint dofs
+        {
+            const double sgn = comp ? -1.0 : 1.0; // the v row is negated (symmetrised system)
+            double *yc = ys + comp * ML;
+            const int mycol = active ? A.colour[patch * PE + le] : -1;
+            for (int c = 0; c < A.ncol; ++c)
+            {
+                if (mycol == c)
+                {
+#pragma unroll
+                    for (int n = 0; n < NN; ++n)
+                        yc[li[n * PE]] += sgn * out[n];
+                }
+                __syncthreads();
+            }
+        }
+
+        // ------------------------------------------------------------ boundary faces:  Au -= w H v,  Av -= w H u
+        {
+            const int f_begin = A.face_off[patch], nf = A.face_off[patch + 1] - f_begin;
+            const double *xo = xs + (1 - comp) * ML; // the other component
+            double *yc = ys + comp * ML;
+            const int nqF = A.nqF;
+            for (int f0 = 0; f0 < nf; f0 += PE)
+            {
+                const int f = f0 + le;
+                const bool fa = f < nf;
+                double res[NB];
+                int fl[NB];
+                int fc = -1;
+#pragma unroll
+                for (int k = 0; k < NB; ++k)
+                {
+                    res[k] = 0.0;
+                    fl[k] = 0;
+                }
+                if (fa)
+                {
+                    const uint16_t *fli = A.face_lidx + (size_t)(f_begin + f) * NB;
+                    const double *af = A.aF + (size_t)nqF * A.face_id[f_begin + f];
+                    fc = A.face_col[f_begin + f];
+                    double w[NB];
+#pragma unroll
+                    for (int k = 0; k < NB; ++k)
+                    {
+                        fl[k] = fli[k];
+                        w[k] = xo[fl[k]];
+                    }
+                    for (int q = 0; q < nqF; ++q)
+                    {
+                        double pv = 0.0;
+#pragma unroll
+                        for (int k = 0; k < NB; ++k)
+                            pv += PF[q + nqF * k] * w[k];
+                        pv *= af[q];
+#pragma unroll
+                        for (int k = 0; k < NB; ++k)
+                            res[k] += PF[q + nqF * k] * pv;
+                    }
+                }
+                for (int c = 0; c < A.nfcol; ++c)
+                {
+                    if (fc == c)
+                    {
+#pragma unroll
+                        for (int k = 0; k < NB; ++k)
+                            yc[fl[k]] -= A.omega * res[k];
+                    }
+                    __syncthreads();
+                }
+            }
+        }
+
+        // ------------------------------------------------------------ write out
+        const int *slot = A.slot_of + off;
+        for (int i = lane; i < nloc; i += 64)
+        {
+            const int s = slot[i];
+            if (s < 0)
+            {
+                const int g = dofs[i];
+                A.y[g] = ys[i];
+                A.y[A.ndof + g] = ys[ML + i];
+            }
+            else
+            {
+                A.part[s] = ys[i];
+                A.part[A.n_slots + s] = ys[ML + i];
+            }
+        }
+    }
+
+    __global__ void __launch_bounds__(256) helm_border_kernel(int n_shared, int ndof, int n_slots, const int *__restrict__ shared_dof,
+                                                             const int *__restrict__ shared_off, const int *__restrict__ shared_slots,
+                                                             const double *__restrict__ part, double *__restrict__ y)
+    {
+        for (int j = blockIdx.x * 256 + threadIdx.x; j < n_shared; j += gridDim.x * 256)
+        {
+            double su = 0.0, sv = 0.0;
+            for (int t = shared_off[j]; t < shared_off[j + 1]; ++t)
+            {
+                const int s = shared_slots[t];
+                su += part[s];
+                sv += part[n_slots + s];
+            }
+            const int g = shared_dof[j];
+            y[g] = su;
+            y[ndof + g] = sv;
+        }
+    }
+
+    // reference layout (c, pt, el) -> [patch][c][pt][32]
+    __global__ void __launch_bounds__(256) repack_kernel(long long total, int comps, int npts, const int *__restrict__ perm,
+                                                        const double *__restrict__ src, double *__restrict__ dst)
+    {
+        for (long long t = blockIdx.x * 256LL + threadIdx.x; t < total; t += gridDim.x * 256LL)
+        {
+            const int le = static_cast<int>(t % PE);
+            long long r = t / PE;
+            const int pt = static_cast<int>(r % npts);
+            r /= npts;
+            const int c = static_cast<int>(r % comps);
+            const long long patch = r / comps;
+            const int el = perm[patch * PE + le];
+            dst[t] = el >= 0 ? src[c + (size_t)comps * (pt + (size_t)npts * el)] : 0.0;
+        }
+    }
+
+    template <typename T>
+    int upload(T **dst, const std::vector<T> &v)
+    {
+        *dst = nullptr;
+        if (v.empty())
+            return 0;
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(dst), v.size() * sizeof(T));
+        if (e != hipSuccess)
+            return static_cast<int>(e);
+        return static_cast<int>(hipMemcpy(*dst, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    }
+
+    int upload_raw(double **dst, const double *src, size_t n)
+    {
+        std::vector<double> v(src, src + n);
+        return upload(dst, v);
+    }
+
+    inline uint32_t spread_bits(uint32_t v)
+    {
+        v &= 0xFFFF;
+        v = (v | (v << 8)) & 0x00FF00FF;
+        v = (v | (v << 4)) & 0x0F0F0F0F;
+        v = (v | (v << 2)) & 0x33333333;
+        v = (v | (v << 1)) & 0x55555555;
+        return v;
+    }
+
+    template <int NB, int NQS, int NQM>
+    void launch_patch(const cuddh_helmholtz_plan *p, const HelmArgs &A, hipStream_t st)
+    {
+        const size_t lds = (size_t)4 * p->max_loc * sizeof(double);
+        hipLaunchKernelGGL((helm_patch_kernel<NB, NQS, NQM>), dim3(p->n_patches), dim3(64), lds, st, A, p->PS, p->DS, p->PM, p->PF);
+    }
+
+    bool supported(int nb, int nqS, int nqM)
+    {
+        return (nb == 3 && nqS == 4 && nqM == 6) || (nb == 4 && nqS == 5 && nqM == 8) || (nb == 5 && nqS == 6 && nqM == 9) ||
+               (nb == 2 && nqS == 3 && nqM == 5);
+    }
+} // namespace
+
+extern "C"
+{
+    int cuddh_hip_helmholtz_plan_destroy(cuddh_helmholtz_plan *p)
+    {
+        if (!p)
+            return 0;
+        void *ptrs[] = {p->dof_off, p->dof_list, p->slot_of, p->patch_nel, p->lidx, p->colour, p->Gp, p->aMp, p->face_off,
+                        p->face_lidx, p->face_id, p->face_col, p->PS, p->DS, p->PM, p->PF, p->shared_dof, p->shared_off,
+                        p->shared_slots, p->part};
+        for (void *q : ptrs)
+            if (q)
+                (void)hipFree(q);
+        delete p;
+        return 0;
+    }
+
+    int cuddh_hip_helmholtz_plan_create(cuddh_helmholtz_plan **out, int ndof, int n_elem, int nb, const int *h_I, const double *h_xy,
+                                        int nqS, const double *h_PS, const double *h_DS, const double *G_S, int nqM,
+                                        const double *h_PM, const double *a_M, int n_faces, const int *h_fI, const int *h_face_elem,
+                                        int nqF, const double *h_PF, const double *a_F)
+    {
+        *out = nullptr;
+        if (!supported(nb, nqS, nqM) || n_elem <= 0)
+            return static_cast<int>(hipErrorNotSupported);
+
+        cuddh_helmholtz_plan *p = new cuddh_helmholtz_plan;
+        p->ndof = ndof;
+        p->n_elem = n_elem;
+        p->nb = nb;
+        p->nqS = nqS;
+        p->nqM = nqM;
+        p->nqF = nqF;
+        p->n_faces = n_faces;
+        p->aF = a_F;
+        const int nn = nb * nb;
+
+        // ---- element order: Morton curve over the centroids
+        std::vector<int> perm(n_elem);
+        for (int e = 0; e < n_elem; ++e)
+            perm[e] = e;
+        if (h_xy)
+        {
+            double lo[2] = {h_xy[0], h_xy[1]}, hi[2] = {h_xy[0], h_xy[1]};
+            for (int e = 0; e < n_elem; ++e)
+                for (int a = 0; a < 2; ++a)
+                {
+                    lo[a] = std::min(lo[a], h_xy[2 * e + a]);
+                    hi[a] = std::max(hi[a], h_xy[2 * e + a]);
+                }
+            std::vector<uint64_t> key(n_elem);
+            for (int e = 0; e < n_elem; ++e)
+            {
+                uint32_t c[2];
+                for (int a = 0; a < 2; ++a)
+                {
+                    const double span = hi[a] - lo[a];
+                    const double t = span > 0 ? (h_xy[2 * e + a] - lo[a]) / span : 0.0;
+                    c[a] = static_cast<uint32_t>(std::min(65535.0, std::max(0.0, t * 65535.0 + 0.5)));
+                }
+                key[e] = (static_cast<uint64_t>(spread_bits(c[0]) | (spread_bits(c[1]) << 1)) << 32) | static_cast<uint32_t>(e);
+            }
+            std::sort(key.begin(), key.end());
+            for (int e = 0; e < n_elem; ++e)
+                perm[e] = static_cast<int>(key[e] & 0xFFFFFFFFu);
+        }
+
+        const int n_patches = (n_elem + PE - 1) / PE;
+        p->n_patches = n_patches;
+        std::vector<int> padded_perm((size_t)n_patches * PE, -1);
+        std::copy(perm.begin(), perm.end(), padded_perm.begin());
+        std::vector<int> patch_of_elem(n_elem);
+        for (int pos = 0; pos < n_elem; ++pos)
+            patch_of_elem[perm[pos]] = pos / PE;
+
+        // ---- faces bucketed by the patch of their element
+        std::vector<int> face_off(n_patches + 1, 0);
+        for (int f = 0; f < n_faces; ++f)
+            face_off[patch_of_elem[h_face_elem[f]] + 1]++;
+        for (int q = 0; q < n_patches; ++q)
+            face_off[q + 1] += face_off[q];
+        std::vector<int> face_id(n_faces);
+        {
+            std::vector<int> cursor(face_off.begin(), face_off.end() - 1);
+            for (int f = 0; f < n_faces; ++f)
+                face_id[cursor[patch_of_elem[h_face_elem[f]]]++] = f;
+        }
+
+        // ---- patch-local numbering, colours
+        std::vector<int> dof_off(n_patches + 1, 0), dof_list, patch_nel(n_patches);
+        std::vector<uint16_t> lidx((size_t)n_patches * nn * PE, 0), face_lidx((size_t)n_faces * nb, 0);
+        std::vector<uint8_t> colour((size_t)n_patches * PE, 0), face_col(n_faces, 0);
+        std::vector<int> stamp(ndof, -1), loc(ndof, 0), touches(ndof, 0);
+        std::vector<uint32_t> used, usedF;
+        int max_loc = 0, ncol = 1, nfcol = 1;
+        dof_list.reserve((size_t)n_elem * nn / 2);
+        for (int q = 0; q < n_patches; ++q)
+        {
+            const int first = static_cast<int>(dof_list.size());
+            dof_off[q] = first;
+            const int nel = std::min(PE, n_elem - q * PE);
+            patch_nel[q] = nel;
+            used.clear();
+            for (int le = 0; le < nel; ++le)
+            {
+                const int *gi = h_I + (size_t)nn * perm[q * PE + le];
+                uint32_t taken = 0;
+                for (int n = 0; n < nn; ++n)
+                {
+                    const int g = gi[n];
+                    if (stamp[g] != q)
+                    {
+                        stamp[g] = q;
+                        loc[g] = static_cast<int>(dof_list.size()) - first;
+                        dof_list.push_back(g);
+                        touches[g]++;
+                        used.push_back(0);
+                    }
+                    lidx[((size_t)q * nn + n) * PE + le] = static_cast<uint16_t>(loc[g]);
+                    taken |= used[loc[g]];
+                }
+                int c = 0;
+                while (c < 31 && (taken >> c & 1u))
+                    ++c;
+                colour[(size_t)q * PE + le] = static_cast<uint8_t>(c);
+                ncol = std::max(ncol, c + 1);
+                for (int n = 0; n < nn; ++n)
+                    used[loc[gi[n]]] |= 1u << c;
+            }
+            const int nloc = static_cast<int>(dof_list.size()) - first;
+            if (nloc > 65535)
+            {
+                cuddh_hip_helmholtz_plan_destroy(p);
+                return static_cast<int>(hipErrorInvalidValue);
+            }
+            max_loc = std::max(max_loc, nloc);
+
+            usedF.assign(nloc, 0);
+            for (int t = face_off[q]; t < face_off[q + 1]; ++t)
+            {
+                const int *fg = h_fI + (size_t)nb * face_id[t];
+                uint32_t taken = 0;
+                for (int k = 0; k < nb; ++k)
+                {
+                    if (stamp[fg[k]] != q)
+                    {
+                        cuddh_hip_helmholtz_plan_destroy(p);
+                        return static_cast<int>(hipErrorInvalidValue); // face dof not in its element's patch
+                    }
+                    face_lidx[(size_t)t * nb + k] = static_cast<uint16_t>(loc[fg[k]]);
+                    taken |= usedF[loc[fg[k]]];
+                }
+                int c = 0;
+                while (c < 31 && (taken >> c & 1u))
+                    ++c;
+                face_col[t] = static_cast<uint8_t>(c);
+                nfcol = std::max(nfcol, c + 1);
+                for (int k = 0; k < nb; ++k)
+                    usedF[loc[fg[k]]] |= 1u << c;
+            }
+        }
+        dof_off[n_patches] = static_cast<int>(dof_list.size());
+        p->max_loc = max_loc;
+        p->ncol = ncol;
+        p->nfcol = n_faces > 0 ? nfcol : 0;
+
+        // ---- dofs touched by more than one patch get one slot per touching patch
+        std::vector<int> shared_index(ndof, -1), shared_dof, shared_off(1, 0);
+        for (int g = 0; g < ndof; ++g)
+            if (touches[g] > 1)
+            {
+                shared_index[g] = static_cast<int>(shared_dof.size());
+                shared_dof.push_back(g);
+                shared_off.push_back(shared_off.back() + touches[g]);
+            }
+        const int n_shared = static_cast<int>(shared_dof.size());
+        const int n_slots = shared_off.back();
+        std::vector<int> slot_of(dof_list.size(), -1), shared_slots(n_slots), fill(shared_off.begin(), shared_off.end() - 1);
+        for (size_t i = 0; i < dof_list.size(); ++i)
+        {
+            const int j = shared_index[dof_list[i]];
+            if (j >= 0)
+            {
+                const int s = fill[j]++;
+                slot_of[i] = s;        // slots of one dof are contiguous and ordered by patch
+                shared_slots[s] = s;
+            }
+        }
+        p->n_shared = n_shared;
+        p->n_slots = n_slots;
+
+        // ---- upload
+        int err = 0;
+        auto ok = [&](int e)
+        {
+            if (e && !err)
+                err = e;
+        };
+        ok(upload(&p->dof_off, dof_off));
+        ok(upload(&p->dof_list, dof_list));
+        ok(upload(&p->slot_of, slot_of));
+        ok(upload(&p->patch_nel, patch_nel));
+        ok(upload(&p->lidx, lidx));
+        ok(upload(&p->colour, colour));
+        ok(upload(&p->face_off, face_off));
+        ok(upload(&p->face_lidx, face_lidx));
+        ok(upload(&p->face_id, face_id));
+        ok(upload(&p->face_col, face_col));
+        ok(upload(&p->shared_dof, shared_dof));
+        ok(upload(&p->shared_off, shared_off));
+        ok(upload(&p->shared_slots, shared_slots));
+        ok(upload_raw(&p->PS, h_PS, (size_t)nqS * nb));
+        ok(upload_raw(&p->DS, h_DS, (size_t)nqS * nb));
+        ok(upload_raw(&p->PM, h_PM, (size_t)nqM * nb));
+        if (n_faces > 0)
+            ok(upload_raw(&p->PF, h_PF, (size_t)nqF * nb));
+        if (n_slots > 0)
+            ok(static_cast<int>(hipMalloc(reinterpret_cast<void **>(&p->part), (size_t)2 * n_slots * sizeof(double))));
+
+        int *d_perm = nullptr;
+        ok(upload(&d_perm, padded_perm));
+        const long long nG = (long long)n_patches * 3 * nqS * nqS * PE, nA = (long long)n_patches * nqM * nqM * PE;
+        ok(static_cast<int>(hipMalloc(reinterpret_cast<void **>(&p->Gp), nG * sizeof(double))));
+        ok(static_cast<int>(hipMalloc(reinterpret_cast<void **>(&p->aMp), nA * sizeof(double))));
+        if (!err)
+        {
+            hipLaunchKernelGGL(repack_kernel, dim3(stream_grid(nG, 256)), dim3(256), 0, nullptr, nG, 3, nqS * nqS, d_perm, G_S, p->Gp);
+            hipLaunchKernelGGL(repack_kernel, dim3(stream_grid(nA, 256)), dim3(256), 0, nullptr, nA, 1, nqM * nqM, d_perm, a_M, p->aMp);
+            ok(launch_status());
+            ok(static_cast<int>(hipDeviceSynchronize()));
+        }
+        if (d_perm)
+            (void)hipFree(d_perm);
+        if (err)
+        {
+            cuddh_hip_helmholtz_plan_destroy(p);
+            return err;
+        }
+
+        p->bytes_alg = (size_t)n_elem * ((size_t)3 * nqS * nqS * 8 + (size_t)nqM * nqM * 8 + (size_t)nn * 4) + (size_t)ndof * 32 +
+                       (size_t)n_faces * ((size_t)nqF * 8 + (size_t)nb * 4);
+        size_t exclusive = 0;
+        for (int s : slot_of)
+            exclusive += s < 0;
+        p->bytes_actual = (size_t)nG * 8 + (size_t)nA * 8 + lidx.size() * 2 + colour.size() + dof_list.size() * (4 + 4 + 16) +
+                          exclusive * 16 + (size_t)n_slots * (16 + 16 + 4) + (size_t)n_shared * (16 + 8) +
+                          (size_t)n_faces * ((size_t)nqF * 8 + (size_t)nb * 2 + 5);
+        *out = p;
+        return 0;
+    }
+
+    int cuddh_hip_helmholtz_apply(const cuddh_helmholtz_plan *p, double omega, const double *x, double *y, void *stream)
+    {
+        if (!p)
+            return static_cast<int>(hipErrorInvalidValue);
+        hipStream_t st = as_stream(stream);
+        HelmArgs A;
+        A.ndof = p->ndof;
+        A.max_loc = p->max_loc;
+        A.ncol = p->ncol;
+        A.nfcol = p->nfcol;
+        A.nqF = p->nqF;
+        A.n_slots = p->n_slots;
+        A.omega = omega;
+        A.dof_off = p->dof_off;
+        A.dof_list = p->dof_list;
+        A.slot_of = p->slot_of;
+        A.patch_nel = p->patch_nel;
+        A.face_off = p->face_off;
+        A.face_id = p->face_id;
+        A.lidx = p->lidx;
+        A.face_lidx = p->face_lidx;
+        A.colour = p->colour;
+        A.face_col = p->face_col;
+        A.Gp = p->Gp;
+        A.aMp = p->aMp;
+        A.aF = p->aF;
+        A.x = x;
+        A.y = y;
+        A.part = p->part;
+
+        if (p->nb == 4)
+            launch_patch<4, 5, 8>(p, A, st);
+        else if (p->nb == 3)
+            launch_patch<3, 4, 6>(p, A, st);
+        else if (p->nb == 5)
+            launch_patch<5, 6, 9>(p, A, st);
+        else
+            launch_patch<2, 3, 5>(p, A, st);
+        int err = launch_status();
+        if (err)
+            return err;
+        if (p->n_shared > 0)
+        {
+            hipLaunchKernelGGL(helm_border_kernel, dim3(stream_grid(p->n_shared, 256)), dim3(256), 0, st, p->n_shared, p->ndof, p->n_slots,
+                               p->shared_dof, p->shared_off, p->shared_slots, p->part, y);
+            err = launch_status();
+        }
+        return err;
+    }
+
+    size_t cuddh_hip_helmholtz_plan_bytes(const cuddh_helmholtz_plan *p, int actual)
+    {
+        return p ? (actual ? p->bytes_actual : p->bytes_alg) : 0;
+    }
+}

@@ -1,0 +1,56 @@
+// Memory and synchronisation entry points of the C ABI.
+#include "common.hpp"
+
+extern "C"
+{
+    int cuddh_hip_malloc_zeroed(void **ptr, size_t bytes)
+    {
+        *ptr = nullptr;
+        if (bytes == 0)
+            return 0;
+        hipError_t e = hipMalloc(ptr, bytes);
+        if (e != hipSuccess)
+            return static_cast<int>(e);
+        e = hipMemset(*ptr, 0, bytes);
+        return static_cast<int>(e);
+    }
+
+    int cuddh_hip_free(void *ptr) { return ptr ? static_cast<int>(hipFree(ptr)) : 0; }
+
+    int cuddh_hip_copy_h2d(void *dst, const void *h_src, size_t bytes)
+    {
+        return bytes ? static_cast<int>(hipMemcpy(dst, h_src, bytes, hipMemcpyHostToDevice)) : 0;
+    }
+
+    int cuddh_hip_copy_d2h(void *h_dst, const void *src, size_t bytes)
+    {
+        return bytes ? static_cast<int>(hipMemcpy(h_dst, src, bytes, hipMemcpyDeviceToHost)) : 0;
+    }
+
+    int cuddh_hip_copy_d2d(void *dst, const void *src, size_t bytes, void *stream)
+    {
+        return bytes ? static_cast<int>(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, cuddh_k::as_stream(stream))) : 0;
+    }
+
+    int cuddh_hip_memset_zero(void *ptr, size_t bytes, void *stream)
+    {
+        return bytes ? static_cast<int>(hipMemsetAsync(ptr, 0, bytes, cuddh_k::as_stream(stream))) : 0;
+    }
+
+    int cuddh_hip_stream_sync(void *stream) { return static_cast<int>(hipStreamSynchronize(cuddh_k::as_stream(stream))); }
+
+    int cuddh_hip_device_sync(void) { return static_cast<int>(hipDeviceSynchronize()); }
+
+    int cuddh_hip_device_count(void)
+    {
+        int n = 0;
+        if (hipGetDeviceCount(&n) != hipSuccess)
+        {
+            (void)hipGetLastError();
+            return 0;
+        }
+        return n;
+    }
+
+    const char *cuddh_hip_error_string(int err) { return hipGetErrorString(static_cast<hipError_t>(err)); }
+}

@@ -1,0 +1,364 @@
+// DDH set-up (host) and the three entry points rhs / action / postprocess.
+// Set-up rules restated from reference source/DDH.cpp:323-609; the local solves
+// themselves are the HIP kernels behind cuddh_hip_ddh_apply_*.
+#include "cuddh/ddh.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <type_traits>
+#include <vector>
+
+#include "cuddh_hip.h"
+
+namespace cuddh
+{
+    namespace detail
+    {
+        namespace
+        {
+            template <typename Real>
+            void geom_setup(int n_domains, int mx_elems, int g_elem, int nb, const int *n_elems, const int *elems,
+                            const double *w, const double *J, Real *G)
+            {
+                int err;
+                if constexpr (std::is_same_v<Real, float>)
+                    err = cuddh_hip_ddh_geom_setup_f32(n_domains, mx_elems, g_elem, nb, n_elems, elems, w, J, G, stream());
+                else
+                    err = cuddh_hip_ddh_geom_setup_f64(n_domains, mx_elems, g_elem, nb, n_elems, elems, w, J, G, stream());
+                check_hip(err, "DDH geometric factors");
+            }
+        } // namespace
+
+        template <typename Real>
+        DDHCore<Real>::DDHCore(double omega_, const double *h_a, const H1Space &fem, int nx, int ny, int kernel)
+            : g_ndof(fem.size()), g_elem(fem.mesh().n_elem()), n_basis(fem.basis().size()), omega(omega_), fem_mesh(&fem.mesh()),
+              fem_basis(&fem.basis())
+        {
+            const int nb = n_basis;
+            if (nb < 2 || nb > 16)
+                cuddh_error("DDH error: n_basis must be in [2, 16].");
+
+            // ---- blocks of nel1d x nel1d elements (16 / nb per side: <= 256 nodes per subdomain)
+            nel1d = std::max(1, 16 / nb);
+            if (nx % nel1d != 0 || ny % nel1d != 0)
+                cuddh_error("DDH error: nx and ny must be multiples of 16 / n_basis.");
+            if (nx * ny != g_elem)
+                cuddh_error("DDH error: nx * ny does not match the mesh.");
+
+            const int ndx = nx / nel1d, ndy = ny / nel1d;
+            n_domains = ndx * ndy;
+            std::vector<int> labels(static_cast<std::size_t>(nx) * ny);
+            for (int j = 0; j < ny; ++j)
+                for (int i = 0; i < nx; ++i)
+                    labels[i + static_cast<std::size_t>(nx) * j] = (i / nel1d) + ndx * (j / nel1d);
+
+            efem.reset(new EnsembleSpace(fem, n_domains, labels.data()));
+
+            // ---- WaveHoltz time grid: dt = 0.1 h / nb^2 shrunk so that nt dt is one period
+            const double T = 2.0 * M_PI / omega;
+            const double h = fem.mesh().min_h();
+            dt = 0.2 * 0.5 * h / (nb * nb);
+            nt = static_cast<int>(std::ceil(T / dt));
+            dt = T / nt;
+
+            _wh_filter.resize(nt + 1);
+            Real *filt = _wh_filter.host_write();
+            for (int k = 0; k <= nt; ++k)
+                filt[k] = static_cast<Real>(dt * (omega / M_PI) * (std::cos(omega * k * dt) - 0.25));
+            filt[0] = static_cast<Real>(filt[0] * 0.5); // trapezoid rule end points
+            filt[nt] = static_cast<Real>(filt[nt] * 0.5);
+
+            _cs.resize(2 * nt + 1);
+            _sn.resize(2 * nt + 1);
+            Real *cs = _cs.host_write();
+            Real *sn = _sn.host_write();
+            for (int k = 0; k <= 2 * nt; ++k)
+            {
+                const double t = 0.5 * k * dt;
+                cs[k] = static_cast<Real>(-std::cos(omega * t));
+                sn[k] = static_cast<Real>(std::sin(omega * t));
+            }
+
+            // ---- extents
+            auto sizes = efem->sizes(MemorySpace::HOST);
+            auto fsizes = efem->fsizes(MemorySpace::HOST);
+            auto s_nel = efem->n_elems(MemorySpace::HOST);
+            mx_dof = mx_fdof = mx_elem_per_dom = 0;
+            for (int s = 0; s < n_domains; ++s)
+            {
+                mx_dof = std::max(mx_dof, sizes(s));
+                mx_fdof = std::max(mx_fdof, fsizes(s));
+                mx_elem_per_dom = std::max(mx_elem_per_dom, s_nel(s));
+            }
+
+            // ---- trace slots.  lambda = (l0, l1, m0, m1): pair k of cmap owns slot k on its first
+            // subdomain's side and slot n_shared + k on the second's; each side reads its own slot and
+            // writes the other's.  Later pairs overwrite earlier ones at cross points (reference quirk:
+            // source/DDH.cpp:436-439), which leaves a few slots unused.
+            auto cmap = efem->connectivity_map(MemorySpace::HOST);
+            const int n_shared = cmap.shape(1);
+            n_lambda = 2 * n_shared;
+
+            _Bf.resize(2 * mx_fdof * n_domains);
+            auto B = reshape(_Bf.host_write(), mx_fdof, 2, n_domains);
+            std::fill(B.begin(), B.end(), -1);
+            for (int k = 0; k < n_shared; ++k)
+            {
+                const int S0 = cmap(0, k), S1 = cmap(1, k), j0 = cmap(2, k), j1 = cmap(3, k);
+                B(j0, 0, S0) = k;
+                B(j0, 1, S0) = n_shared + k;
+                B(j1, 0, S1) = n_shared + k;
+                B(j1, 1, S1) = k;
+            }
+
+            // ---- renumber each subdomain so that its face dofs come first (in face-space order)
+            auto faceproj = efem->face_proj(MemorySpace::HOST);
+            auto g_inds = efem->global_indices(MemorySpace::HOST);
+            auto s_inds = efem->subspace_indices(MemorySpace::HOST);
+            auto s_elems = efem->elements(MemorySpace::HOST);
+
+            _gI.resize(mx_dof * n_domains);
+            auto gI = reshape(_gI.host_write(), mx_dof, n_domains);
+            _sI.resize(nb * nb * mx_elem_per_dom * n_domains);
+            auto sI = reshape(_sI.host_write(), nb, nb, mx_elem_per_dom, n_domains);
+
+            std::vector<int> new_of_old(mx_dof);
+            for (int s = 0; s < n_domains; ++s)
+            {
+                const int nd = sizes(s), nf = fsizes(s);
+                std::fill(new_of_old.begin(), new_of_old.end(), -1);
+                int next = 0;
+                for (; next < nf; ++next)
+                {
+                    const int old = faceproj(next, s);
+                    new_of_old[old] = next;
+                    gI(next, s) = g_inds(old, s);
+                }
+                for (int old = 0; old < nd; ++old)
+                    if (new_of_old[old] < 0)
+                    {
+                        new_of_old[old] = next;
+                        gI(next, s) = g_inds(old, s);
+                        ++next;
+                    }
+                for (int el = 0; el < s_nel(s); ++el)
+                    for (int l = 0; l < nb; ++l)
+                        for (int k = 0; k < nb; ++k)
+                            sI(k, l, el, s) = new_of_old[s_inds(k, l, el, s)];
+            }
+
+            // ---- local operators
+            const Basis &basis = fem.basis();
+            const QuadratureRule &q = basis.quadrature();
+
+            _D.resize(nb * nb);
+            {
+                dmat Dd(nb, nb);
+                basis.deriv(nb, q.x(), Dd);
+                Real *hD = _D.host_write();
+                for (int i = 0; i < nb * nb; ++i)
+                    hD[i] = static_cast<Real>(Dd[i]);
+            }
+
+            const auto &metrics = fem.mesh().element_metrics(q);
+            auto detJ = reshape(metrics.measures(MemorySpace::HOST), nb, nb, g_elem);
+            auto fem_gi = fem.global_indices(MemorySpace::HOST);
+
+            // global lumped mass and its inverse
+            std::vector<double> inv_mass(g_ndof, 0.0);
+            for (int el = 0; el < g_elem; ++el)
+                for (int j = 0; j < nb; ++j)
+                    for (int i = 0; i < nb; ++i)
+                        inv_mass[fem_gi(i, j, el)] += q.w(i) * q.w(j) * detJ(i, j, el);
+            for (auto &v : inv_mass)
+                v = 1.0 / v;
+
+            _m.resize(mx_dof * n_domains);
+            _H.resize(mx_fdof * n_domains);
+            _a.resize(mx_dof * n_domains);
+            _gmi.resize(mx_dof * n_domains);
+            auto m = reshape(_m.host_write(), mx_dof, n_domains);
+            auto H = reshape(_H.host_write(), mx_fdof, n_domains);
+            auto A = reshape(_a.host_write(), mx_dof, n_domains);
+            auto gmi = reshape(_gmi.host_write(), mx_dof, n_domains);
+
+            auto faces = efem->faces(MemorySpace::HOST);
+            auto n_faces = efem->n_faces(MemorySpace::HOST);
+            auto f_inds = efem->face_indices(MemorySpace::HOST);
+
+            for (int s = 0; s < n_domains; ++s)
+            {
+                // the storage type accumulates, as in the reference (float += double)
+                for (int el = 0; el < s_nel(s); ++el)
+                {
+                    const int g_el = s_elems(el, s);
+                    for (int j = 0; j < nb; ++j)
+                        for (int i = 0; i < nb; ++i)
+                        {
+                            Real &acc = m(sI(i, j, el, s), s);
+                            acc = static_cast<Real>(acc + q.w(i) * q.w(j) * detJ(i, j, g_el));
+                        }
+                }
+                for (int i = 0; i < sizes(s); ++i)
+                {
+                    A(i, s) = static_cast<Real>(h_a[gI(i, s)]);
+                    gmi(i, s) = static_cast<Real>(inv_mass[gI(i, s)]);
+                }
+                for (int f = 0; f < n_faces(s); ++f)
+                {
+                    const Edge *edge = fem.mesh().edge(faces(f, s));
+                    for (int i = 0; i < nb; ++i)
+                    {
+                        Real &acc = H(f_inds(i, f, s), s);
+                        acc = static_cast<Real>(acc + edge->measure(q.x(i)) * q.w(i));
+                    }
+                }
+            }
+
+            requested_kernel = kernel;
+        }
+
+        template <typename Real>
+        DDHCore<Real>::~DDHCore()
+        {
+            if (plan)
+                cuddh_hip_ddh_plan_destroy(plan);
+        }
+
+        template <typename Real>
+        void DDHCore<Real>::ensure_plan() const
+        {
+            if (plan)
+                return;
+            const int nb = n_basis;
+            const QuadratureRule &q = fem_basis->quadrature();
+
+            // geometric factors G (3, nb*nb*mx_elems, n_domains) from the Jacobians at the GLL points
+            host_device_dvec w(nb);
+            double *hw = w.host_write();
+            for (int i = 0; i < nb; ++i)
+                hw[i] = q.w(i);
+            const double *d_J = fem_mesh->element_metrics(q).jacobians(MemorySpace::DEVICE);
+            _g_tensor.resize(3 * nb * nb * mx_elem_per_dom * n_domains);
+            geom_setup<Real>(n_domains, mx_elem_per_dom, g_elem, nb, efem->n_elems(MemorySpace::DEVICE),
+                             efem->elements(MemorySpace::DEVICE), w.device_read(), d_J, _g_tensor.device_write());
+            check_hip(cuddh_hip_stream_sync(stream()), "DDH geometric factors");
+
+            cuddh_ddh_desc d;
+            d.g_ndof = g_ndof;
+            d.n_domains = n_domains;
+            d.n_lambda = n_lambda;
+            d.nb = nb;
+            d.nel1d = nel1d;
+            d.mx_dof = mx_dof;
+            d.mx_fdof = mx_fdof;
+            d.nt = nt;
+            d.omega = omega;
+            d.dt = dt;
+            d.s_dof = efem->sizes(MemorySpace::DEVICE);
+            d.s_fdof = efem->fsizes(MemorySpace::DEVICE);
+            d.B = _Bf.device_read();
+            d.gI = _gI.device_read();
+            d.sI = _sI.device_read();
+            d.D = _D.device_read();
+            d.G = _g_tensor.device_read();
+            d.m = _m.device_read();
+            d.gmi = _gmi.device_read();
+            d.a = _a.device_read();
+            d.H = _H.device_read();
+            d.wh_filter = _wh_filter.device_read();
+            d.cs = _cs.device_read();
+            d.sn = _sn.device_read();
+            check_hip(cuddh_hip_ddh_plan_create(&plan, &d, std::is_same_v<Real, double> ? 1 : 0, requested_kernel),
+                      "DDH plan");
+        }
+
+        template <typename Real>
+        int DDHCore<Real>::kernel_kind() const
+        {
+            ensure_plan();
+            return cuddh_hip_ddh_plan_kernel(plan);
+        }
+
+        template <typename Real>
+        void DDHCore<Real>::solve(int d0, int d1, const double *x, double *y, bool zero_y, const Real *lambda, Real *update) const
+        {
+            ensure_plan();
+            int err;
+            if constexpr (std::is_same_v<Real, float>)
+                err = cuddh_hip_ddh_apply_f32(plan, d0, d1, x, y, zero_y ? 1 : 0, lambda, update, stream());
+            else
+                err = cuddh_hip_ddh_apply_f64(plan, d0, d1, x, y, zero_y ? 1 : 0, lambda, update, stream());
+            check_hip(err, "DDH local solves");
+        }
+
+        template class DDHCore<float>;
+        template class DDHCore<double>;
+    } // namespace detail
+
+    // ------------------------------------------------------------ DDH (fp32, reference precision)
+
+    DDH::DDH(double omega, const double *h_a, const H1Space &fem, int nx, int ny) : core(omega, h_a, fem, nx, ny, 0) {}
+    DDH::DDH(double omega, const double *h_a, const H1Space &fem, int nx, int ny, int kernel)
+        : core(omega, h_a, fem, nx, ny, kernel)
+    {
+    }
+
+    void DDH::action(const float *x, float *y) const
+    {
+        core.solve(0, core.num_domains(), nullptr, nullptr, false, x, y);
+        axpby(size(), 1.0f, x, -1.0f, y); // y = lambda - T lambda
+    }
+
+    void DDH::rhs(const double *f, float *b) const { core.solve(0, core.num_domains(), f, nullptr, false, nullptr, b); }
+
+    void DDH::postprocess(const float *lambda, const double *f, double *u) const
+    {
+        core.solve(0, core.num_domains(), f, u, true, lambda, nullptr);
+    }
+
+    void DDH::local_traces(int d0, int d1, const double *f, const float *lambda, float *update) const
+    {
+        core.solve(d0, d1, f, nullptr, false, lambda, update);
+    }
+
+    void DDH::local_solution(int d0, int d1, const float *lambda, const double *f, double *u, bool zero_u) const
+    {
+        core.solve(d0, d1, f, u, zero_u, lambda, nullptr);
+    }
+
+    // ------------------------------------------------------------ DDH64 (fp64 parity mode)
+
+    DDH64::DDH64(double omega, const double *h_a, const H1Space &fem, int nx, int ny, int kernel)
+        : core(omega, h_a, fem, nx, ny, kernel)
+    {
+    }
+
+    void DDH64::action(const double *x, double *y) const
+    {
+        core.solve(0, core.num_domains(), nullptr, nullptr, false, x, y);
+        axpby(size(), 1.0, x, -1.0, y);
+    }
+
+    void DDH64::action(double, const double *, double *) const
+    {
+        cuddh_error("DDH64::action(c, x, y) is not defined for the substructured operator.");
+    }
+
+    void DDH64::rhs(const double *f, double *b) const { core.solve(0, core.num_domains(), f, nullptr, false, nullptr, b); }
+
+    void DDH64::postprocess(const double *lambda, const double *f, double *u) const
+    {
+        core.solve(0, core.num_domains(), f, u, true, lambda, nullptr);
+    }
+
+    void DDH64::local_traces(int d0, int d1, const double *f, const double *lambda, double *update) const
+    {
+        core.solve(d0, d1, f, nullptr, false, lambda, update);
+    }
+
+    void DDH64::local_solution(int d0, int d1, const double *lambda, const double *f, double *u, bool zero_u) const
+    {
+        core.solve(d0, d1, f, u, zero_u, lambda, nullptr);
+    }
+} // namespace cuddh

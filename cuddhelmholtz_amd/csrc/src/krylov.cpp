@@ -1,0 +1,248 @@
+// Restarted GMRES.  Iteration semantics follow reference source/gmres.cpp:91-235
+// (see krylov.hpp); the arithmetic is scheduled differently: the k+1 projection
+// coefficients of an Arnoldi step stay on the device (each axpy reads its
+// coefficient from device memory) and reach the host in one copy per step.
+#include "cuddh/krylov.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <string>
+
+#include "cuddh_hip.h"
+
+namespace cuddh
+{
+    namespace
+    {
+        // ---- scalar-type dispatch onto the C ABI
+        inline int k_dot(int n, const double *x, const double *y, double *r, void *ws) { return cuddh_hip_dot_f64(n, x, y, r, ws, stream()); }
+        inline int k_dot(int n, const float *x, const float *y, float *r, void *ws) { return cuddh_hip_dot_f32(n, x, y, r, ws, stream()); }
+        inline int k_nrm2(int n, const double *x, double *r, void *ws) { return cuddh_hip_nrm2_f64(n, x, r, ws, stream()); }
+        inline int k_nrm2(int n, const float *x, float *r, void *ws) { return cuddh_hip_nrm2_f32(n, x, r, ws, stream()); }
+        inline int k_axpby_dev(int n, double sa, const double *a, const double *x, double b, double *y) { return cuddh_hip_axpby_dev_f64(n, sa, a, x, b, y, stream()); }
+        inline int k_axpby_dev(int n, float sa, const float *a, const float *x, float b, float *y) { return cuddh_hip_axpby_dev_f32(n, sa, a, x, b, y, stream()); }
+        inline int k_scal_inv_dev(int n, const double *a, double *x) { return cuddh_hip_scal_inv_dev_f64(n, a, x, stream()); }
+        inline int k_scal_inv_dev(int n, const float *a, float *x) { return cuddh_hip_scal_inv_dev_f32(n, a, x, stream()); }
+
+        // apply the k previous rotations to column h, then build rotation k that zeroes h[k+1]
+        template <typename scalar>
+        void rotate_column(scalar *h, scalar *cs, scalar *sn, int k)
+        {
+            for (int i = 0; i < k; ++i)
+            {
+                const scalar a = h[i], b = h[i + 1];
+                h[i] = cs[i] * a + sn[i] * b;
+                h[i + 1] = cs[i] * b - sn[i] * a;
+            }
+            const scalar r = std::hypot(h[k], h[k + 1]);
+            cs[k] = h[k] / r;
+            sn[k] = h[k + 1] / r;
+            h[k] = cs[k] * h[k] + sn[k] * h[k + 1];
+            h[k + 1] = 0;
+        }
+
+        // back substitution R y = g for the leading kk x kk block of the (ld x m) column-major array R
+        // (the reference calls LAPACK ?trsv('U','N','N'), source/gmres.cpp:26-41)
+        template <typename scalar>
+        void back_substitute(int kk, const scalar *R, int ld, scalar *g)
+        {
+            for (int i = kk - 1; i >= 0; --i)
+            {
+                scalar s = g[i];
+                for (int j = i + 1; j < kk; ++j)
+                    s -= R[i + ld * j] * g[j];
+                g[i] = s / R[i + ld * i];
+            }
+        }
+
+        class LeftPreconditioned : public Operator
+        {
+        public:
+            LeftPreconditioned(int n, const Operator *A_, const Operator *P_) : tmp(n), A(A_), P(P_) {}
+
+            void action(double, const double *, double *) const override
+            {
+                cuddh_error("gmres: the preconditioned system only supports action(x, y).");
+            }
+
+            void action(const double *x, double *y) const override
+            {
+                double *q = tmp.device_write();
+                A->action(x, q);
+                P->action(q, y);
+            }
+
+        private:
+            mutable host_device_dvec tmp;
+            const Operator *A;
+            const Operator *P;
+        };
+
+        template <typename scalar, typename Op>
+        solver_out arnoldi_restarted(int n, scalar *x, const Op *A, const scalar *b, int m, int maxit, scalar tol, int verbose,
+                                     double max_seconds)
+        {
+            using clock = std::chrono::high_resolution_clock;
+            const scalar one = 1, zero = 0;
+            const int m1 = m + 1;
+
+            const scalar bnrm = norm(n, b);
+
+            HostDeviceArray<scalar> r_store(n), V_store(n * m1), col_store(m1 + 1);
+            scalar *r = r_store.device_write();
+            scalar *V = V_store.device_write();
+            scalar *dcol = col_store.device_write(); // Hessenberg column under construction, on the device
+
+            void *ws = nullptr;
+            detail::check_hip(cuddh_hip_malloc_zeroed(&ws, cuddh_hip_reduce_ws_bytes()), "gmres workspace");
+            struct Guard
+            {
+                void *p;
+                ~Guard() { cuddh_hip_free(p); }
+            } guard{ws};
+
+            std::vector<scalar> H(static_cast<std::size_t>(m1) * m, 0), cs(m, 0), sn(m, 0), eta(m1, 0);
+
+            solver_out out;
+            out.success = false;
+            out.num_iter = 0;
+            out.num_matvec = 0;
+            out.res_norm.reserve(maxit + 1);
+            out.time.reserve(maxit + 1);
+
+            A->action(x, r);
+            out.num_matvec++;
+            axpby(n, one, b, -one, r); // r = b - A x
+            scalar r_nrm = norm(n, r);
+
+            out.res_norm.push_back(static_cast<double>(r_nrm));
+            out.time.push_back(0.0);
+            const auto t0 = clock::now();
+
+            if (r_nrm < tol * bnrm)
+            {
+                out.success = true;
+                if (verbose)
+                    std::cout << "After 0 iterations, GMRES achieved rel. residual of " << out.res_norm.back() / bnrm
+                              << "\nGMRES successfully converged within desired tolerance." << std::endl;
+                return out;
+            }
+
+            if (verbose)
+                std::cout << std::setprecision(5) << std::scientific;
+
+            int it = 1;
+            for (; it < maxit; ++it)
+            {
+                axpby(n, one / r_nrm, r, zero, V); // v0 = r / ||r||
+                std::fill(eta.begin(), eta.end(), zero);
+                eta[0] = r_nrm;
+
+                int k1 = 0;
+                for (int k = 0; k < m; ++k)
+                {
+                    k1 = k + 1;
+                    scalar *vk = V + static_cast<std::size_t>(k) * n;
+                    scalar *vk1 = vk + n;
+
+                    A->action(vk, vk1);
+                    out.num_matvec++;
+
+                    // modified Gram-Schmidt against v0..vk, coefficients kept on the device
+                    for (int j = 0; j < k1; ++j)
+                    {
+                        const scalar *vj = V + static_cast<std::size_t>(j) * n;
+                        detail::check_hip(k_dot(n, vk1, vj, dcol + j, ws), "gmres dot");
+                        detail::check_hip(k_axpby_dev(n, -one, dcol + j, vj, one, vk1), "gmres axpy");
+                    }
+                    detail::check_hip(k_nrm2(n, vk1, dcol + k1, ws), "gmres norm");
+                    // normalise on the device before the host has seen the norm; on breakdown (norm == 0)
+                    // v_{k+1} becomes non-finite but is never used
+                    detail::check_hip(k_scal_inv_dev(n, dcol + k1, vk1), "gmres scal");
+
+                    scalar *h = H.data() + static_cast<std::size_t>(m1) * k;
+                    detail::check_hip(cuddh_hip_stream_sync(stream()), "gmres sync");
+                    detail::check_hip(cuddh_hip_copy_d2h(h, dcol, sizeof(scalar) * (k1 + 1)), "gmres column copy");
+
+                    if (h[k1] == zero)
+                        break;
+
+                    rotate_column(h, cs.data(), sn.data(), k);
+                    eta[k1] = -sn[k] * eta[k];
+                    eta[k] = cs[k] * eta[k];
+
+                    if (std::abs(eta[k1]) < tol * bnrm)
+                        break;
+                }
+
+                back_substitute(k1, H.data(), m1, eta.data());
+                for (int k = 0; k < k1; ++k)
+                    axpby(n, eta[k], V + static_cast<std::size_t>(k) * n, one, x);
+
+                A->action(x, r);
+                out.num_matvec++;
+                axpby(n, one, b, -one, r);
+                r_nrm = norm(n, r);
+
+                out.res_norm.push_back(static_cast<double>(r_nrm));
+                const double elapsed = std::chrono::duration<double>(clock::now() - t0).count();
+                out.time.push_back(elapsed);
+                if (elapsed > max_seconds)
+                    break;
+
+                if (verbose == 1)
+                {
+                    const int width = 30;
+                    const int filled = std::min(width, width * it / std::max(1, maxit - 1));
+                    std::cout << "[" << std::string(filled, '#') << std::string(width - filled, ' ') << "] || iteration "
+                              << std::setw(10) << it + 1 << " / " << maxit << " || rel. res. = " << std::setw(10)
+                              << r_nrm / bnrm << "\r" << std::flush;
+                }
+                else if (verbose >= 2)
+                {
+                    std::cout << "iteration " << std::setw(10) << it + 1 << " / " << maxit
+                              << " || rel. res. = " << std::setw(10) << r_nrm / bnrm << std::endl;
+                }
+
+                if (r_nrm < tol * bnrm)
+                {
+                    out.success = true;
+                    break;
+                }
+            }
+
+            if (verbose == 1)
+                std::cout << std::endl;
+            if (verbose)
+                std::cout << "After " << it << " iterations, GMRES achieved rel. residual of " << out.res_norm.back() / bnrm
+                          << (out.success ? "\nGMRES successfully converged within desired tolerance."
+                                          : "\nGMRES failed to converge within desired tolerance.")
+                          << std::endl;
+
+            out.num_iter = it;
+            return out;
+        }
+    } // namespace
+
+    solver_out gmres(int n, double *x, const Operator *A, const double *b, int m, int maxit, double tol, int verbose,
+                     double max_seconds)
+    {
+        return arnoldi_restarted<double>(n, x, A, b, m, maxit, tol, verbose, max_seconds);
+    }
+
+    solver_out gmres(int n, double *x, const Operator *A, const double *b, const Operator *Precond, int m, int maxit,
+                     double tol, int verbose, double max_seconds)
+    {
+        LeftPreconditioned PA(n, A, Precond);
+        host_device_dvec Pb(n);
+        double *d_Pb = Pb.device_write();
+        Precond->action(b, d_Pb);
+        return arnoldi_restarted<double>(n, x, &PA, d_Pb, m, maxit, tol, verbose, max_seconds);
+    }
+
+    solver_out gmres(int n, float *x, const SinglePrecisionOperator *A, const float *b, int m, int maxit, float tol,
+                     int verbose, double max_seconds)
+    {
+        return arnoldi_restarted<float>(n, x, A, b, m, maxit, tol, verbose, max_seconds);
+    }
+} // namespace cuddh

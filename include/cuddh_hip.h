@@ -1,0 +1,210 @@
+/*
+ * cuddh_hip.h -- C ABI of the MI355X (gfx950) kernel layer.
+ *
+ * Every entry point is `extern "C"`, takes plain pointers and sizes, returns an
+ * int (0 = success, otherwise the hipError_t value) and takes the HIP stream as
+ * an opaque `void*` last argument (NULL = the null stream).  All array
+ * arguments are DEVICE pointers unless the name starts with `h_`.  Layouts are
+ * column major (first index fastest), exactly the layouts the reference's
+ * operator classes already hold in their HostDeviceArray members, so that a
+ * maintainer can replace the body of each reference `action()` by one call
+ * (see INTEGRATION.md).  Citations are relative to the reference repository
+ * arotem3/CuDDHelmholtz.
+ *
+ * None of these functions allocates, frees or synchronises unless its comment
+ * says so (safe to capture in a hipGraph).
+ */
+#ifndef CUDDH_HIP_H
+#define CUDDH_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ runtime */
+
+/* Replaces the cudaMalloc/cudaMemset/cudaMemcpy/cudaFree calls of
+ * include/HostDeviceArray.hpp:143,189,259-262,269,296-299.  Blocking. */
+int cuddh_hip_malloc_zeroed(void **ptr, size_t bytes);
+int cuddh_hip_free(void *ptr);
+int cuddh_hip_copy_h2d(void *dst, const void *h_src, size_t bytes);
+int cuddh_hip_copy_d2h(void *h_dst, const void *src, size_t bytes);
+int cuddh_hip_copy_d2d(void *dst, const void *src, size_t bytes, void *stream);
+/* include/linalg.hpp:46-48 (zeros -> cudaMemset) */
+int cuddh_hip_memset_zero(void *ptr, size_t bytes, void *stream);
+int cuddh_hip_stream_sync(void *stream);
+int cuddh_hip_device_sync(void);
+/* number of visible devices; 0 if there is no GPU (never fails) */
+int cuddh_hip_device_count(void);
+const char *cuddh_hip_error_string(int err);
+
+/* ------------------------------------------------------------------ BLAS-1
+ * source/linalg.cpp:51-201.  `ws` is a caller-owned device workspace of at
+ * least cuddh_hip_reduce_ws_bytes() bytes used for the two-stage reduction;
+ * `result` is a DEVICE scalar (no host sync, no allocation -- the reference
+ * allocates, memsets and D2H-copies a scalar per call, source/linalg.cpp:67-83).
+ */
+size_t cuddh_hip_reduce_ws_bytes(void);
+int cuddh_hip_axpby_f64(int n, double a, const double *x, double b, double *y, void *stream);
+int cuddh_hip_axpby_f32(int n, float a, const float *x, float b, float *y, void *stream);
+/* y <- (sa * *a_dev) * x + b * y with the coefficient read from device memory
+ * (lets the modified Gram-Schmidt loop of source/gmres.cpp:167-172 run without
+ * a host round trip per dot product). */
+int cuddh_hip_axpby_dev_f64(int n, double sa, const double *a_dev, const double *x, double b, double *y, void *stream);
+int cuddh_hip_axpby_dev_f32(int n, float sa, const float *a_dev, const float *x, float b, float *y, void *stream);
+/* x <- x / *a_dev   (source/gmres.cpp:179 with H(k+1,k) left on the device) */
+int cuddh_hip_scal_inv_dev_f64(int n, const double *a_dev, double *x, void *stream);
+int cuddh_hip_scal_inv_dev_f32(int n, const float *a_dev, float *x, void *stream);
+int cuddh_hip_dot_f64(int n, const double *x, const double *y, double *result, void *ws, void *stream);
+int cuddh_hip_dot_f32(int n, const float *x, const float *y, float *result, void *ws, void *stream);
+/* result <- sqrt(sum x[i]^2) */
+int cuddh_hip_nrm2_f64(int n, const double *x, double *result, void *ws, void *stream);
+int cuddh_hip_nrm2_f32(int n, const float *x, float *result, void *ws, void *stream);
+/* result <- sum (x[i]-y[i])^2  (square root taken by the caller; source/linalg.cpp:103-137) */
+int cuddh_hip_sqdist_f64(int n, const double *x, const double *y, double *result, void *ws, void *stream);
+int cuddh_hip_sqdist_f32(int n, const float *x, const float *y, float *result, void *ws, void *stream);
+int cuddh_hip_copy_f64(int n, const double *x, double *y, void *stream);
+int cuddh_hip_copy_f32(int n, const float *x, float *y, void *stream);
+int cuddh_hip_copy_i32(int n, const int *x, int *y, void *stream);
+int cuddh_hip_scal_f64(int n, double a, double *x, void *stream);
+int cuddh_hip_scal_f32(int n, float a, float *x, void *stream);
+int cuddh_hip_fill_f64(int n, double a, double *x, void *stream);
+int cuddh_hip_fill_f32(int n, float a, float *x, void *stream);
+int cuddh_hip_fill_i32(int n, int a, int *x, void *stream);
+/* y[i] (+)= c * p[i] * x[i]; accumulate != 0 selects +=.  x may alias y.
+ * source/MassMatrix.cpp:316-334, source/FaceMassMatrix.cpp:303-321 */
+int cuddh_hip_diag_scale_f64(int n, int accumulate, double c, const double *p, const double *x, double *y, void *stream);
+/* x[i] <- 1 / x[i]   (source/MassMatrix.cpp:276-279) */
+int cuddh_hip_reciprocal_f64(int n, double *x, void *stream);
+
+/* ------------------------------------------------------------------ index maps
+ * source/H1Space.cpp:189-219 (FaceSpace::restrict / prolong / orth) */
+int cuddh_hip_gather_f64(int n, const int *proj, const double *x, double *y, void *stream);      /* y[i]  = x[proj[i]] */
+int cuddh_hip_scatter_add_f64(int n, const int *proj, const double *x, double *y, void *stream); /* y[proj[i]] += x[i] */
+int cuddh_hip_zero_indexed_f64(int n, const int *proj, double *x, void *stream);                 /* x[proj[i]] = 0 */
+
+/* ------------------------------------------------------------------ element operators (fp64)
+ * Shapes: P,D (nq,nb); I (nb,nb,n_elem); J (2,2,nq,nq,n_elem); detJ (nq,nq,n_elem);
+ * G (3,nq,nq,n_elem); a (nq,nq,n_elem); w (nq). */
+
+/* source/StiffnessMatrix.cpp:5-38  (setup_geometric_factors) */
+int cuddh_hip_stiffness_setup(int n_elem, int nq, const double *w, const double *J, double *G, void *stream);
+/* source/StiffnessMatrix.cpp:83-205  y[I] += c * S x */
+int cuddh_hip_stiffness_apply(int n_elem, int nq, int nb, const double *P, const double *D, const double *G,
+                              const int *I, double c, const double *x, double *y, void *stream);
+/* source/MassMatrix.cpp:5-67  (init_mass_matrix); coef may be NULL (=1) */
+int cuddh_hip_mass_setup(int n_elem, int nq, int nb, const double *coef, const double *detJ, const double *w,
+                         const int *I, const double *P, double *a, void *stream);
+/* source/MassMatrix.cpp:137-239  y[I] += c * M x */
+int cuddh_hip_mass_apply(int n_elem, int nq, int nb, const int *I, const double *P, const double *a, double c,
+                         const double *x, double *y, void *stream);
+/* source/MassMatrix.cpp:241-280 (init_diag_mass): op <- 1 / lumped mass.  Zero-fills op first. */
+int cuddh_hip_diag_mass_setup(int ndof, int n_elem, int nb, const double *coef, const double *detJ, const double *w,
+                              const int *I, double *op, void *stream);
+/* source/FaceMassMatrix.cpp:5-49; I (nb,n_faces); detJ (nq,n_faces); a (nq,n_faces) */
+int cuddh_hip_facemass_setup(int n_faces, int nb, int nq, const double *w, const double *P, const double *detJ,
+                             const double *coef, const int *I, double *a, void *stream);
+/* source/FaceMassMatrix.cpp:141-223 */
+int cuddh_hip_facemass_apply(int n_faces, int nb, int nq, const double *P, const double *a, const int *I, double c,
+                             const double *x, double *y, void *stream);
+/* source/FaceMassMatrix.cpp:225-255 (init_diag); op must be zero on entry (the reference relies on that too) */
+int cuddh_hip_diag_facemass_setup(int ndof, int n_faces, int nb, const double *w, const double *detJ,
+                                  const double *coef, const int *I, double *op, void *stream);
+
+/* ------------------------------------------------------------------ fused complex Helmholtz apply
+ * One launch pair for  [u;v] -> [Au;Av]  of examples/Helmholtz.hpp:28-56
+ * (2 memsets + 11 launches there).  The plan owns patch-ordered copies of the
+ * index map and of the metric arrays (layout in DESIGN.md).  create/destroy
+ * allocate, copy and synchronise; apply does not.
+ *
+ * h_I (nb,nb,n_elem) HOST; h_xy optional HOST element centroids (2,n_elem) used
+ * only to order elements into compact patches (NULL = keep element order);
+ * G_S (3,nqS,nqS,n_elem), a_M (nqM,nqM,n_elem) DEVICE arrays as produced by
+ * cuddh_hip_stiffness_setup / cuddh_hip_mass_setup; boundary-face data:
+ * h_fI (nb,n_faces) HOST face -> H1 global index (already composed with the
+ * FaceSpace projection), h_face_elem (n_faces) HOST element each face belongs to
+ * (Edge::elements[0]), a_F (nqF,n_faces) DEVICE from cuddh_hip_facemass_setup.
+ * Returns hipErrorNotSupported (801) for (nb,nqS,nqM) combinations without a
+ * specialised kernel; callers then use the separate operators.
+ */
+typedef struct cuddh_helmholtz_plan cuddh_helmholtz_plan;
+int cuddh_hip_helmholtz_plan_create(cuddh_helmholtz_plan **plan, int ndof, int n_elem, int nb, const int *h_I,
+                                    const double *h_xy, int nqS, const double *h_PS, const double *h_DS,
+                                    const double *G_S, int nqM, const double *h_PM, const double *a_M,
+                                    int n_faces, const int *h_fI, const int *h_face_elem, int nqF, const double *h_PF,
+                                    const double *a_F);
+int cuddh_hip_helmholtz_plan_destroy(cuddh_helmholtz_plan *plan);
+/* y = [ S u - w^2 M u - w H v ;  -(S v - w^2 M v + w H u) ],  x = [u;v], y = [Au;Av], each of length ndof */
+int cuddh_hip_helmholtz_apply(const cuddh_helmholtz_plan *plan, double omega, const double *x, double *y, void *stream);
+/* bytes the plan's apply reads+writes per call, by the SURVEY 8d formula and as actually laid out */
+size_t cuddh_hip_helmholtz_plan_bytes(const cuddh_helmholtz_plan *plan, int actual);
+
+/* ------------------------------------------------------------------ DDH local solves
+ * source/DDH.cpp:15-58 (init_geom_factors): G (3, nb*nb*mx_elems, n_domains) as
+ * Real triples (the reference stores float3), from J (2,2,nb,nb,g_elem). */
+int cuddh_hip_ddh_geom_setup_f32(int n_domains, int mx_elems, int g_elem, int nb, const int *n_elems, const int *elems,
+                                 const double *w, const double *J, float *G, void *stream);
+int cuddh_hip_ddh_geom_setup_f64(int n_domains, int mx_elems, int g_elem, int nb, const int *n_elems, const int *elems,
+                                 const double *w, const double *J, double *G, void *stream);
+
+/* The arrays DDH holds after its constructor (include/DDH.hpp:55-83,
+ * source/DDH.cpp:425-608), in the reference's own layouts.  `real` is float for
+ * *_f32 and double for *_f64.  All DEVICE pointers. */
+typedef struct cuddh_ddh_desc
+{
+    int g_ndof;      /* global H1 dofs */
+    int n_domains;   /* subdomains (one LDS/register-resident local solve each) */
+    int n_lambda;    /* 2 * n_shared */
+    int nb;          /* n_basis */
+    int nel1d;       /* elements per subdomain edge (NEL); mx_elems = nel1d^2 */
+    int mx_dof;      /* leading dimension of gI, m, gmi, a */
+    int mx_fdof;     /* leading dimension of B, H */
+    int nt;          /* time steps per period */
+    double omega;
+    double dt;
+    const int *s_dof;      /* (n_domains) subdomain sizes          EnsembleSpace::sizes  */
+    const int *s_fdof;     /* (n_domains) face-space sizes         EnsembleSpace::fsizes */
+    const int *B;          /* (mx_fdof, 2, n_domains) read/write lambda slots, -1 = none  source/DDH.cpp:425-440 */
+    const int *gI;         /* (mx_dof, n_domains) permuted subdomain dof -> global dof     source/DDH.cpp:486-497 */
+    const int *sI;         /* (nb, nb, mx_elems, n_domains) element node -> permuted subdomain dof  :489-509 */
+    const void *D;         /* real (nb, nb) GLL differentiation matrix  :523-528 */
+    const void *G;         /* real (3, nb*nb*mx_elems, n_domains)       :530-537 */
+    const void *m;         /* real (mx_dof, n_domains) lumped subdomain mass  :541-584 */
+    const void *gmi;       /* real (mx_dof, n_domains) global inverse lumped mass :559-591 */
+    const void *a;         /* real (mx_dof, n_domains) coefficient      :589 */
+    const void *H;         /* real (mx_fdof, n_domains) lumped face mass :593-607 */
+    const void *wh_filter; /* real (nt+1)   :370-375 */
+    const void *cs;        /* real (2nt+1)  :377-386 */
+    const void *sn;        /* real (2nt+1) */
+} cuddh_ddh_desc;
+
+typedef struct cuddh_ddh_plan cuddh_ddh_plan;
+/* Builds the device-side tables the kernels need on top of the descriptor
+ * (deterministic owner-gather lists replacing the LDS atomics of
+ * source/DDH.cpp:108; structure check for the wave-per-subdomain kernel).
+ * Allocates and synchronises.  is_f64 selects the arithmetic type of `desc`.
+ * kernel: 0 = auto, 1 = generic (one workgroup per subdomain, LDS),
+ *         2 = wave (one wavefront per subdomain, registers + DPP; nb == 4 only). */
+int cuddh_hip_ddh_plan_create(cuddh_ddh_plan **plan, const cuddh_ddh_desc *desc, int is_f64, int kernel);
+int cuddh_hip_ddh_plan_destroy(cuddh_ddh_plan *plan);
+/* which kernel the plan resolved to (1 or 2) */
+int cuddh_hip_ddh_plan_kernel(const cuddh_ddh_plan *plan);
+
+/* source/DDH.cpp:111-321 (ddh_action + stiffness).  x: forcing [F;G] (2*g_ndof
+ * doubles) or NULL; y: solution output [u;v] (2*g_ndof doubles, zero-filled by
+ * the call) or NULL; lambda: traces (2*n_lambda) or NULL; update: outgoing
+ * traces (2*n_lambda) or NULL.  Only subdomains [dom_begin, dom_end) are solved
+ * (the whole range for a single GPU; a rank's shard for the multi-GPU path).
+ * If y != NULL and zero_y != 0 the call zero-fills y first (source/DDH.cpp:144).
+ */
+int cuddh_hip_ddh_apply_f32(const cuddh_ddh_plan *plan, int dom_begin, int dom_end, const double *x, double *y,
+                            int zero_y, const float *lambda, float *update, void *stream);
+int cuddh_hip_ddh_apply_f64(const cuddh_ddh_plan *plan, int dom_begin, int dom_end, const double *x, double *y,
+                            int zero_y, const double *lambda, double *update, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CUDDH_HIP_H */
