@@ -1,0 +1,423 @@
+"""Python mirror of the reference's operator interface for the hot path.
+
+Same names and argument meaning as the C++ classes of cuddh.hpp (Mesh2D, Basis,
+H1Space, FaceSpace, EnsembleSpace, StiffnessMatrix, MassMatrix, FaceMassMatrix,
+DDH, gmres); every method forwards to libcuddh_amd.so.  Device vectors are
+torch CUDA tensors (torch is only the allocator / stream provider); host arrays
+are numpy.  Column-major (Fortran) shapes throughout, as in the reference.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import _native as N
+
+lib = N.lib
+
+
+def _ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise ValueError("expected a CUDA tensor")
+    if not t.is_contiguous():
+        raise ValueError("expected a contiguous tensor")
+    return C.c_void_p(t.data_ptr())
+
+
+def _h(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def use_torch_stream() -> None:
+    """Make the library launch on torch's current CUDA stream."""
+    import torch
+
+    lib.cuddh_set_stream(C.c_void_p(torch.cuda.current_stream().cuda_stream))
+
+
+def device_count() -> int:
+    return int(lib.cuddh_hip_device_count())
+
+
+def quadrature(n: int, kind: str = "lobatto"):
+    x = np.empty(n)
+    w = np.empty(n)
+    N.check_capi(lib.cuddh_quadrature(n, 0 if kind == "legendre" else 1, _h(x), _h(w)), "quadrature")
+    return x, w
+
+
+class Basis:
+    def __init__(self, n: int):
+        self.n = n
+        self._h = N.handle(lib.cuddh_basis_create(n), "Basis")
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib.cuddh_basis_destroy(self._h)
+            self._h = None
+
+    def size(self) -> int:
+        return self.n
+
+    def eval(self, x) -> np.ndarray:
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        P = np.empty((len(x), self.n), order="F")
+        N.check_capi(lib.cuddh_basis_eval(self._h, len(x), _h(x), _h(P)), "Basis.eval")
+        return P
+
+    def deriv(self, x) -> np.ndarray:
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        D = np.empty((len(x), self.n), order="F")
+        N.check_capi(lib.cuddh_basis_deriv(self._h, len(x), _h(x), _h(D)), "Basis.deriv")
+        return D
+
+
+class Mesh2D:
+    def __init__(self, handle):
+        self._h = handle
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib.cuddh_mesh_destroy(self._h)
+            self._h = None
+
+    @staticmethod
+    def uniform_rect(nx, ax, bx, ny, ay, by) -> "Mesh2D":
+        return Mesh2D(N.handle(lib.cuddh_mesh_uniform_rect(nx, ax, bx, ny, ay, by), "Mesh2D.uniform_rect"))
+
+    @staticmethod
+    def from_vertices(xy: np.ndarray, elems: np.ndarray) -> "Mesh2D":
+        """xy: (2, n_pts) F-order or (n_pts, 2) C-order; elems: (n_elem, 4) C-order vertex ids."""
+        xy = np.ascontiguousarray(xy, dtype=np.float64)
+        elems = np.ascontiguousarray(elems, dtype=np.int32)
+        return Mesh2D(N.handle(lib.cuddh_mesh_from_vertices(xy.size // 2, _h(xy), elems.size // 4, _h(elems)), "Mesh2D.from_vertices"))
+
+    def n_elem(self):
+        return lib.cuddh_mesh_n_elem(self._h)
+
+    def n_edges(self):
+        return lib.cuddh_mesh_n_edges(self._h)
+
+    def n_nodes(self):
+        return lib.cuddh_mesh_n_nodes(self._h)
+
+    def min_h(self):
+        return lib.cuddh_mesh_min_h(self._h)
+
+    def boundary_edges(self) -> np.ndarray:
+        out = np.empty(lib.cuddh_mesh_n_boundary_edges(self._h), dtype=np.int32)
+        N.check_capi(lib.cuddh_mesh_boundary_edges(self._h, _h(out)))
+        return out
+
+    def edges(self) -> np.ndarray:
+        """(n_edges, 8): type(1=boundary), node0, node1, elem0, elem1, side0, side1, delta"""
+        out = np.empty((self.n_edges(), 8), dtype=np.int32)
+        N.check_capi(lib.cuddh_mesh_edges(self._h, _h(out)))
+        return out
+
+
+class H1Space:
+    def __init__(self, mesh: Mesh2D, basis: Basis):
+        self.mesh, self.basis = mesh, basis
+        self._h = N.handle(lib.cuddh_h1space_create(mesh._h, basis._h), "H1Space")
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib.cuddh_h1space_destroy(self._h)
+            self._h = None
+
+    def size(self) -> int:
+        return lib.cuddh_h1space_size(self._h)
+
+    def global_indices(self) -> np.ndarray:
+        nb = self.basis.n
+        I = np.empty((nb, nb, self.mesh.n_elem()), dtype=np.int32, order="F")
+        N.check_capi(lib.cuddh_h1space_global_indices(self._h, _h(I)))
+        return I
+
+    def physical_coordinates(self) -> np.ndarray:
+        X = np.empty((2, self.size()), order="F")
+        N.check_capi(lib.cuddh_h1space_coordinates(self._h, _h(X)))
+        return X
+
+
+class FaceSpace:
+    def __init__(self, fem: H1Space, faces):
+        self.fem = fem
+        self.faces = np.ascontiguousarray(faces, dtype=np.int32)
+        self._h = N.handle(lib.cuddh_facespace_create(fem._h, len(self.faces), _h(self.faces)), "FaceSpace")
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib.cuddh_facespace_destroy(self._h)
+            self._h = None
+
+    def size(self):
+        return lib.cuddh_facespace_size(self._h)
+
+    def n_faces(self):
+        return len(self.faces)
+
+    def subspace_indices(self) -> np.ndarray:
+        I = np.empty((self.fem.basis.n, len(self.faces)), dtype=np.int32, order="F")
+        N.check_capi(lib.cuddh_facespace_subspace_indices(self._h, _h(I)))
+        return I
+
+    def global_indices(self) -> np.ndarray:
+        p = np.empty(self.size(), dtype=np.int32)
+        N.check_capi(lib.cuddh_facespace_global_indices(self._h, _h(p)))
+        return p
+
+    def restrict(self, x, y):
+        N.check_capi(lib.cuddh_facespace_restrict(self._h, _ptr(x), _ptr(y)), "restrict")
+
+    def prolong(self, x, y):
+        N.check_capi(lib.cuddh_facespace_prolong(self._h, _ptr(x), _ptr(y)), "prolong")
+
+    def orth(self, x):
+        N.check_capi(lib.cuddh_facespace_orth(self._h, _ptr(x)), "orth")
+
+
+class EnsembleSpace:
+    _SHAPES = {
+        "gI": lambda d, nb: (d[3], d[0]),
+        "sizes": lambda d, nb: (d[0],),
+        "elements": lambda d, nb: (d[1], d[0]),
+        "n_elems": lambda d, nb: (d[0],),
+        "faces": lambda d, nb: (d[2], d[0]),
+        "n_faces": lambda d, nb: (d[0],),
+        "sI": lambda d, nb: (nb, nb, d[1], d[0]),
+        "fI": lambda d, nb: (nb, d[2], d[0]),
+        "pI": lambda d, nb: (d[4], d[0]),
+        "fsizes": lambda d, nb: (d[0],),
+        "cmap": lambda d, nb: (4, d[5]),
+    }
+
+    def __init__(self, fem: H1Space, n_spaces: int, labels):
+        self.fem = fem
+        labels = np.ascontiguousarray(labels, dtype=np.int32)
+        self._h = N.handle(lib.cuddh_ensemble_create(fem._h, n_spaces, _h(labels)), "EnsembleSpace")
+        d = np.empty(6, dtype=np.int32)
+        N.check_capi(lib.cuddh_ensemble_dims(self._h, _h(d)))
+        self.dims = d
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib.cuddh_ensemble_destroy(self._h)
+            self._h = None
+
+    def array(self, name: str) -> np.ndarray:
+        shape = self._SHAPES[name](self.dims, self.fem.basis.n)
+        out = np.empty(shape, dtype=np.int32, order="F")
+        if out.size:
+            N.check_capi(lib.cuddh_ensemble_array(self._h, name.encode(), _h(out)))
+        return out
+
+
+class _Operator:
+    """y = A x (`action(x, y)`) and y += c A x (`action(c, x, y)`) on device vectors."""
+
+    def __init__(self, handle, keepalive=()):
+        self._h = handle
+        self._keep = keepalive
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib.cuddh_operator_destroy(self._h)
+            self._h = None
+
+    def action(self, *args):
+        if len(args) == 2:
+            x, y = args
+            N.check_capi(lib.cuddh_operator_apply(self._h, _ptr(x), _ptr(y)), "action")
+        else:
+            c, x, y = args
+            N.check_capi(lib.cuddh_operator_apply_add(self._h, float(c), _ptr(x), _ptr(y)), "action")
+
+
+class StiffnessMatrix(_Operator):
+    def __init__(self, fem: H1Space, nq: int = 0):
+        super().__init__(N.handle(lib.cuddh_stiffness_create(fem._h, nq), "StiffnessMatrix"), (fem,))
+
+
+class MassMatrix(_Operator):
+    def __init__(self, fem: H1Space, a=None):
+        super().__init__(N.handle(lib.cuddh_mass_create(fem._h, _ptr(a)), "MassMatrix"), (fem, a))
+
+
+class DiagInvMassMatrix(_Operator):
+    def __init__(self, fem: H1Space, a=None):
+        super().__init__(N.handle(lib.cuddh_diaginv_mass_create(fem._h, _ptr(a)), "DiagInvMassMatrix"), (fem, a))
+
+
+class FaceMassMatrix(_Operator):
+    def __init__(self, fs: FaceSpace, a=None):
+        super().__init__(N.handle(lib.cuddh_facemass_create(fs._h, _ptr(a)), "FaceMassMatrix"), (fs, a))
+
+
+class DiagInvFaceMassMatrix(_Operator):
+    def __init__(self, fs: FaceSpace, a=None):
+        super().__init__(N.handle(lib.cuddh_diaginv_facemass_create(fs._h, _ptr(a)), "DiagInvFaceMassMatrix"), (fs, a))
+
+
+class HelmholtzOperator(_Operator):
+    """Fused [u;v] -> [Au;Av] of reference examples/Helmholtz.hpp:28-56."""
+
+    def __init__(self, omega: float, a2x, ax, fem: H1Space, fs: FaceSpace):
+        super().__init__(N.handle(lib.cuddh_helmholtz_create(float(omega), _ptr(a2x), _ptr(ax), fem._h, fs._h), "HelmholtzOperator"),
+                         (fem, fs, a2x, ax))
+
+    def action_unfused(self, x, y):
+        N.check_capi(lib.cuddh_helmholtz_apply_unfused(self._h, _ptr(x), _ptr(y)), "action_unfused")
+
+    def fused(self) -> bool:
+        return bool(lib.cuddh_helmholtz_is_fused(self._h))
+
+    def bytes_per_apply(self, actual: bool = False) -> int:
+        return int(lib.cuddh_helmholtz_bytes(self._h, 1 if actual else 0))
+
+
+# integrand ids of cuddh_capi.h
+GAUSSIANS, ALPHA_DISK, MASS_POLY, STIFF_NEG_LAPLACIAN, STIFF_FUNC, CONSTANT, ALPHA_DISK_SQ = range(7)
+
+
+def linear_functional(fem: H1Space, integrand: int, F, param: float = 0.0, nq: int = 0, c: float = 1.0, accumulate: bool = False):
+    N.check_capi(lib.cuddh_linear_functional(fem._h, nq, integrand, float(param), float(c), int(accumulate), _ptr(F)), "LinearFunctional")
+
+
+def face_linear_functional(fs: FaceSpace, integrand: int, F, param: float = 0.0, nq: int = 0, c: float = 1.0, accumulate: bool = False):
+    N.check_capi(lib.cuddh_face_linear_functional(fs._h, nq, integrand, float(param), float(c), int(accumulate), _ptr(F)), "FaceLinearFunctional")
+
+
+def nodal_values(fem: H1Space, integrand: int, out, param: float = 0.0):
+    N.check_capi(lib.cuddh_nodal_values(fem._h, integrand, float(param), _ptr(out)), "nodal_values")
+
+
+@dataclass
+class SolverOut:
+    success: bool
+    num_iter: int
+    num_matvec: int
+    res_norm: list = field(default_factory=list)
+    time: list = field(default_factory=list)
+
+
+def _solver_out(res: N.SolverResult, h_res, h_time) -> SolverOut:
+    n = res.n_res
+    return SolverOut(bool(res.success), res.num_iter, res.num_matvec, list(h_res[:n]), list(h_time[:n]))
+
+
+class DDH:
+    """Substructured Helmholtz solver (reference include/DDH.hpp).  precision 'f32' is the
+    reference's; 'f64' is the parity mode with double traces."""
+
+    _INT_TABLES = ("B", "gI", "sI")
+
+    def __init__(self, omega: float, h_a: np.ndarray, fem: H1Space, nx: int, ny: int, precision: str = "f32", kernel: int = 0):
+        self.fem = fem
+        self.f64 = precision == "f64"
+        h_a = np.ascontiguousarray(h_a, dtype=np.float64)
+        self._h = N.handle(lib.cuddh_ddh_create(float(omega), _h(h_a), fem._h, nx, ny, int(self.f64), kernel), "DDH")
+        self.omega = float(omega)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib.cuddh_ddh_destroy(self._h)
+            self._h = None
+
+    def size(self) -> int:
+        return lib.cuddh_ddh_size(self._h)
+
+    @property
+    def trace_dtype(self):
+        import torch
+
+        return torch.float64 if self.f64 else torch.float32
+
+    def info(self) -> dict:
+        info = np.zeros(8, dtype=np.int32)
+        dt = C.c_double()
+        N.check_capi(lib.cuddh_ddh_info(self._h, _h(info), C.byref(dt)), "DDH.info")
+        keys = ("n_domains", "nt", "n_lambda", "mx_dof", "mx_fdof", "nel1d", "kernel", "is_f64")
+        out = dict(zip(keys, map(int, info)))
+        out["dt"] = dt.value
+        return out
+
+    def table(self, name: str) -> np.ndarray:
+        n = lib.cuddh_ddh_table(self._h, name.encode(), None, 1)
+        if n < 0:
+            raise RuntimeError(N.last_error())
+        dtype = np.int32 if name in self._INT_TABLES else (np.float64 if self.f64 else np.float32)
+        out = np.empty(int(n), dtype=dtype)
+        if n:
+            lib.cuddh_ddh_table(self._h, name.encode(), _h(out), 0)
+        return out
+
+    def rhs(self, f, b):
+        N.check_capi(lib.cuddh_ddh_rhs(self._h, _ptr(f), _ptr(b)), "DDH.rhs")
+
+    def postprocess(self, lam, f, u):
+        N.check_capi(lib.cuddh_ddh_postprocess(self._h, _ptr(lam), _ptr(f), _ptr(u)), "DDH.postprocess")
+
+    def action(self, x, y):
+        N.check_capi(lib.cuddh_ddh_action(self._h, _ptr(x), _ptr(y)), "DDH.action")
+
+    def local_traces(self, d0, d1, f, lam, update):
+        N.check_capi(lib.cuddh_ddh_local_traces(self._h, d0, d1, _ptr(f), _ptr(lam), _ptr(update)), "DDH.local_traces")
+
+    def local_solution(self, d0, d1, lam, f, u, zero_u=True):
+        N.check_capi(lib.cuddh_ddh_local_solution(self._h, d0, d1, _ptr(lam), _ptr(f), _ptr(u), int(zero_u)), "DDH.local_solution")
+
+
+def gmres(n: int, x, A, b, m: int, maxit: int, tol: float = 1e-6, verbose: int = 0, max_seconds: float = 6 * 60 * 60, Precond=None) -> SolverOut:
+    """Restarted GMRES (reference include/gmres.hpp:33-36).  A: an operator of this module, a DDH,
+    or a Python callable `A(x, y)` acting on device tensors of x's dtype."""
+    import torch
+
+    res = N.SolverResult()
+    h_res = np.zeros(maxit + 2)
+    h_time = np.zeros(maxit + 2)
+    if isinstance(A, DDH):
+        N.check_capi(lib.cuddh_gmres_ddh(n, _ptr(x), A._h, _ptr(b), m, maxit, float(tol), verbose, float(max_seconds), C.byref(res), _h(h_res), _h(h_time)), "gmres")
+    elif isinstance(A, _Operator):
+        N.check_capi(lib.cuddh_gmres_f64(n, _ptr(x), A._h, _ptr(b), Precond._h if Precond is not None else None, m, maxit, float(tol), verbose,
+                                         float(max_seconds), C.byref(res), _h(h_res), _h(h_time)), "gmres")
+    else:
+        dtype = x.dtype
+        is64 = dtype == torch.float64
+        dev = x.device
+        errors = []
+
+        def wrap(ptr, count):
+            # view of library-owned device memory as a tensor (no copy)
+            return torch.as_tensor(_DevArray(ptr, count, is64), device=dev)
+
+        def cb(ctx, xp, yp):
+            try:
+                A(wrap(xp, n), wrap(yp, n))
+            except Exception as e:  # noqa: BLE001 - must not propagate through C
+                errors.append(e)
+
+        cfun = N.ACTION_CB(cb)
+        N.check_capi(lib.cuddh_gmres_callback(n, _ptr(x), cfun, None, _ptr(b), int(is64), m, maxit, float(tol), verbose, float(max_seconds),
+                                              C.byref(res), _h(h_res), _h(h_time)), "gmres")
+        if errors:
+            raise errors[0]
+    return _solver_out(res, h_res, h_time)
+
+
+class _DevArray:
+    """Minimal __cuda_array_interface__ carrier so torch can view library-owned device memory."""
+
+    def __init__(self, ptr: int, count: int, is64: bool):
+        self.__cuda_array_interface__ = {
+            "shape": (count,),
+            "typestr": "<f8" if is64 else "<f4",
+            "data": (int(ptr), False),
+            "version": 2,
+        }
