@@ -1,0 +1,310 @@
+#!/usr/bin/env python3
+"""Benchmark of the CuDDHelmholtz hot path on MI355X.
+
+Workload (BASELINE.json metric): DDH-GMRES at omega = 32 pi on a 1024 x 1024 structured
+square, n_basis = 4 ("p = 4" in the vocabulary of the reference's tests, Basis(p); the only
+reading reference DDH supports), fp32 local solves (the reference's precision), GMRES(20).
+
+  step   = one Arnoldi step of GMRES(20) on the substructured operator: one DDH::action
+           (65,536 WaveHoltz subdomain solves, sharded over the ranks) + modified Gram-Schmidt
+           against the current Krylov basis (k cycles 0..19).  The once-per-20-steps restart
+           bookkeeping (host triangular solve, true-residual matvec) is not in the loop.
+  value  = 2 * g_ndof * steps / seconds   [DoF.iter/s], whole job, MAX time over ranks.
+  N > 1  = subdomains split into contiguous ranges, one per rank; every rank keeps the whole
+           (26 MB) trace vector, local solves write only their own slots, one RCCL all-reduce
+           (sum with zeros) per step reassembles it.  Total work fixed -> "strong" scaling.
+
+Extra objects on the same JSON line:
+  roofline     = the global operator apply (fused complex Helmholtz apply on the same mesh),
+                 the HBM-bound kernel of the path: algorithmic bytes / measured launch time.
+  ddh_kernel   = the dominant kernel of `value` (not HBM-bound): fp32 FLOP rate vs vector peak.
+  cpu_baseline = the oracle's restatement of the local solves timed on the host cores on a
+                 bounded sample of subdomains (rank 0, N = 1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import math
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+FP32_VECTOR_PEAK_TF = 157.3  # MI355X_MICROARCH.md chip-level parameters
+
+
+def ddh_flops_per_subdomain_step(nb: int, nel: int) -> float:
+    """fp32 FLOPs of one RK2 time step of one subdomain as the algorithm is defined
+    (source/DDH.cpp:60-109, 247-292): two stiffness sweeps + the update, per element node."""
+    nodes = nb * nb * nel * nel
+    sweep = nodes * (2 * 2 * nb + 6 + 2 * 2 * nb + 1)  # derivatives, flux, test functions, assembly add
+    update = nodes * 26
+    return 2.0 * sweep + update
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--nx", type=int, default=1024, help="elements per side (default: the metric's 1024)")
+    ap.add_argument("--nb", type=int, default=4)
+    ap.add_argument("--kernel", type=int, default=0, help="DDH kernel: 0 auto, 1 workgroup, 2 wavefront")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import cuddhelmholtz_amd as cd
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    cd.use_torch_stream()
+
+    nx, nb = args.nx, args.nb
+    omega = math.pi * nx / 32.0  # 32 pi at 1024, 16 pi at 512 (BASELINE.json configs 3 and 4)
+    gmres_m = 20
+
+    # ---------------------------------------------------------------- problem set-up (untimed)
+    t_setup = time.time()
+    mesh = cd.Mesh2D.uniform_rect(nx, -1.0, 1.0, nx, -1.0, 1.0)
+    basis = cd.Basis(nb)
+    fem = cd.H1Space(mesh, basis)
+    ndof = fem.size()
+    f = torch.zeros(2 * ndof, dtype=torch.float64, device=dev)
+    a = torch.zeros(ndof, dtype=torch.float64, device=dev)
+    cd.linear_functional(fem, cd.GAUSSIANS, f[:ndof], param=omega)  # examples/DDH.cpp:120
+    cd.linear_functional(fem, cd.ALPHA_DISK, a)                      # examples/DDH.cpp:122-123
+    mi = cd.DiagInvMassMatrix(fem)
+    mi.action(a, a)
+    h_a = a.cpu().numpy()
+    F = cd.DDH(omega, h_a, fem, nx, nx, precision="f32", kernel=args.kernel)
+    info = F.info()
+    n = F.size()
+    nd = info["n_domains"]
+    d0, d1 = (nd * rank) // world, (nd * (rank + 1)) // world
+
+    b = torch.zeros(n, dtype=torch.float32, device=dev)
+    F.local_traces(d0, d1, f, None, b)  # rhs, sharded
+    if world > 1:
+        dist.all_reduce(b)
+    torch.cuda.synchronize()
+    t_setup = time.time() - t_setup
+
+    # ---------------------------------------------------------------- Arnoldi steps
+    from cuddhelmholtz_amd import _native as N
+
+    lib = N.lib
+    V = torch.zeros((gmres_m + 1, n), dtype=torch.float32, device=dev)
+    hcol = torch.zeros(gmres_m + 2, dtype=torch.float32, device=dev)
+    ws = torch.zeros(lib.cuddh_hip_reduce_ws_bytes() // 4, dtype=torch.float32, device=dev)
+    upd = torch.zeros(n, dtype=torch.float32, device=dev)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+
+    V[0].copy_(b / torch.linalg.norm(b))
+
+    def arnoldi_step(k: int) -> None:
+        vk, vk1 = V[k], V[k + 1]
+        # w = (I - T) v_k : local solves of this rank's subdomains, then reassemble the trace vector
+        upd.zero_()
+        F.local_traces(d0, d1, None, vk, upd)
+        if world > 1:
+            dist.all_reduce(upd)
+        N.check(lib.cuddh_hip_copy_f32(n, p(vk), p(vk1), st))
+        N.check(lib.cuddh_hip_axpby_f32(n, -1.0, p(upd), 1.0, p(vk1), st))
+        for j in range(k + 1):
+            N.check(lib.cuddh_hip_dot_f32(n, p(vk1), p(V[j]), p(hcol[j:]), p(ws), st))
+            N.check(lib.cuddh_hip_axpby_dev_f32(n, -1.0, p(hcol[j:]), p(V[j]), 1.0, p(vk1), st))
+        N.check(lib.cuddh_hip_nrm2_f32(n, p(vk1), p(hcol[k + 1:]), p(ws), st))
+        N.check(lib.cuddh_hip_scal_inv_dev_f32(n, p(hcol[k + 1:]), p(vk1), st))
+        if k + 1 == gmres_m:  # restart: continue from the last basis vector
+            V[0].copy_(vk1)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    step_id = 0
+    for _ in range(args.warmup):
+        arnoldi_step(step_id % gmres_m)
+        step_id += 1
+    barrier()
+    t0 = time.perf_counter()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for _ in range(args.steps):
+        arnoldi_step(step_id % gmres_m)
+        step_id += 1
+    ev1.record()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    finite = bool(torch.isfinite(V).all().item())
+
+    value = 2.0 * ndof * args.steps / elapsed
+    ms_per_step = 1e3 * elapsed / args.steps
+
+    # DDH kernel rate (device time of the timed loop is > 99 % local solves)
+    flops_step = ddh_flops_per_subdomain_step(nb, info["nel1d"]) * 5 * info["nt"] * nd
+    ddh_tf = flops_step * args.steps / elapsed / 1e12 / world
+
+    result = {
+        "metric": "DDH-GMRES DoF*iter/s",
+        "value": value,
+        "unit": "DoF*iter/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": f"DDH-GMRES(20) Arnoldi steps, omega={omega / math.pi:g}pi, {nx}x{nx} quads uniform_rect, n_basis={nb} "
+                        f"(reference tests' Basis(p) reading of p={nb}), {nd} reference-size subdomains "
+                        f"({info['nel1d']}x{info['nel1d']} elements each), nt={info['nt']} RK2 steps x 5 WaveHoltz iterations per action",
+            "g_ndof": ndof,
+            "n_traces": n,
+            "ddh_kernel": {1: "workgroup-per-subdomain", 2: "wavefront-per-subdomain"}.get(info["kernel"], str(info["kernel"])),
+            "sharding": f"{world} contiguous subdomain ranges, all-reduce of the trace vector per step" if world > 1 else "single GPU",
+            "setup_seconds": round(t_setup, 2),
+            "finite": finite,
+        },
+        "ddh_kernel": {
+            "bound": "fp32-valu/lds (not HBM-bound; SURVEY 8d)",
+            "achieved": ddh_tf,
+            "peak": FP32_VECTOR_PEAK_TF,
+            "unit": "TFLOP/s per GPU",
+            "frac": ddh_tf / FP32_VECTOR_PEAK_TF,
+            "flops_per_action": flops_step,
+        },
+    }
+
+    # ---------------------------------------------------------------- roofline: the global operator apply
+    if rank == 0 and not args.no_roofline:
+        result["roofline"] = helmholtz_roofline(cd, torch, dev, fem, mesh, omega, ndof)
+
+    # ---------------------------------------------------------------- CPU baseline (oracle), N = 1 only
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(F, info, ndof, nb, omega, args.cpu_seconds)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+
+
+def helmholtz_roofline(cd, torch, dev, fem, mesh, omega, ndof):
+    """HBM roofline of the fused complex Helmholtz apply (examples/Helmholtz.hpp:28-56 semantics) on the
+    benchmark mesh, coefficient a = 1.  Launch time from HIP events on the stream
+    the kernels are launched on."""
+    faces = mesh.boundary_edges()
+    fs = cd.FaceSpace(fem, faces)
+    a2 = torch.ones(ndof, dtype=torch.float64, device=dev)
+    ax = torch.ones(fs.size(), dtype=torch.float64, device=dev)
+    A = cd.HelmholtzOperator(omega, a2, ax, fem, fs)
+    g = torch.Generator(device="cpu").manual_seed(12345)
+    x = (2.0 * torch.rand(2 * ndof, generator=g, dtype=torch.float64) - 1.0).to(dev)
+    y = torch.empty_like(x)
+    for _ in range(5):
+        A.action(x, y)
+    torch.cuda.synchronize()
+    reps = 30
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        A.action(x, y)
+    e1.record()
+    torch.cuda.synchronize()
+    t = e0.elapsed_time(e1) * 1e-3 / reps
+    b_alg = A.bytes_per_apply(False)
+    gbs = b_alg / t / 1e9
+    return {
+        "bound": "hbm",
+        "kernel": "helm_patch_kernel + helm_border_kernel (fused complex Helmholtz apply)" if A.fused() else "unfused operator sequence",
+        "achieved": gbs,
+        "peak": HBM_PEAK_GBS,
+        "unit": "GB/s",
+        "frac": gbs / HBM_PEAK_GBS,
+        "traffic": None,
+        "algorithmic_bytes": b_alg,
+        "layout_bytes": A.bytes_per_apply(True),
+        "seconds_per_apply": t,
+        "complex_dof_per_s": ndof / t,
+    }
+
+
+def cpu_baseline(F, info, ndof, nb, omega, budget_s):
+    """The oracle's restatement of the DDH local solves (oracle/ddh_body.inc, OpenMP over subdomains)
+    on the product's own constructor tables, for a bounded sample of subdomains with the full nt."""
+    import oracle
+
+    lib = oracle.lib()
+    threads = oracle.num_threads()
+    nd, nt = info["n_domains"], info["nt"]
+    tabs = {k: F.table(k) for k in ("B", "gI", "sI", "D", "G", "m", "gmi", "a", "H", "filter", "cs", "sn")}
+    nel = info["nel1d"]
+    s_dof = np.full(nd, info["mx_dof"], dtype=np.int32)
+    s_fdof = np.full(nd, info["mx_fdof"], dtype=np.int32)
+    lam = np.zeros(2 * info["n_lambda"], dtype=np.float32)
+    lam[::7] = 1.0
+    upd = np.zeros_like(lam)
+    pp = lambda arr: arr.ctypes.data_as(C.c_void_p)  # noqa: E731
+
+    def run(count):
+        t0 = time.perf_counter()
+        lib.orc_ddh_apply_f32(C.c_int(ndof), C.c_int(nd), C.c_int(info["n_lambda"]), C.c_int(nb), C.c_int(nel * nel), C.c_int(info["mx_dof"]),
+                              C.c_int(info["mx_fdof"]), C.c_int(nt), C.c_double(omega), C.c_double(info["dt"]), pp(s_dof), pp(s_fdof), pp(tabs["B"]),
+                              pp(tabs["gI"]), pp(tabs["sI"]), pp(tabs["D"]), pp(tabs["G"]), pp(tabs["m"]), pp(tabs["gmi"]), pp(tabs["a"]),
+                              pp(tabs["H"]), pp(tabs["filter"]), pp(tabs["cs"]), pp(tabs["sn"]), None, None, pp(lam), pp(upd), C.c_int(0), C.c_int(count))
+        return time.perf_counter() - t0
+
+    t1 = run(threads)  # calibration: one subdomain per thread
+    count = int(max(threads, min(nd, threads * max(1.0, budget_s / max(t1, 1e-3)))))
+    count = (count // threads) * threads
+    t = run(count)
+    sub_per_s = count / t
+    value = 2.0 * ndof * (sub_per_s / nd)
+    return {
+        "value": value,
+        "unit": "DoF*iter/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"oracle fp32 local solves of {count} of {nd} subdomains (full nt={nt}, 5 WaveHoltz iterations) in {t:.1f} s, "
+                  f"OpenMP over subdomains; extrapolated to one DDH::action over all subdomains; Krylov BLAS-1 excluded",
+        "subdomain_solves_per_s": sub_per_s,
+    }
+
+
+if __name__ == "__main__":
+    main()
