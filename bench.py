@@ -57,7 +57,7 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--nx", type=int, default=1024, help="elements per side (default: the metric's 1024)")
     ap.add_argument("--nb", type=int, default=4)
-    ap.add_argument("--kernel", type=int, default=0, help="DDH kernel: 0 auto, 1 workgroup, 2 wavefront")
+    ap.add_argument("--kernel", type=int, default=0, help="DDH kernel: 0 auto, 1 workgroup, 2 wavefront, 3 wavefront with DPP-folded FMAs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -194,7 +194,7 @@ def main() -> None:
                         f"({info['nel1d']}x{info['nel1d']} elements each), nt={info['nt']} RK2 steps x 5 WaveHoltz iterations per action",
             "g_ndof": ndof,
             "n_traces": n,
-            "ddh_kernel": {1: "workgroup-per-subdomain", 2: "wavefront-per-subdomain"}.get(info["kernel"], str(info["kernel"])),
+            "ddh_kernel": {1: "workgroup-per-subdomain", 2: "wavefront-per-subdomain", 3: "wavefront-per-subdomain, DPP-folded FMAs"}.get(info["kernel"], str(info["kernel"])),
             "sharding": f"{world} contiguous subdomain ranges, all-reduce of the trace vector per step" if world > 1 else "single GPU",
             "setup_seconds": round(t_setup, 2),
             "finite": finite,

@@ -24,6 +24,10 @@ INCLUDES = [ROOT / "include", CSRC / "include", CSRC / "kernels"]
 COMMON = ["-O3", "-std=c++17", "-fPIC", "-DNDEBUG", "-Wall", "-Wno-unused-parameter", "-Wno-unused-function"]
 HIP_FLAGS = ["-x", "hip", f"--offload-arch={ARCH}", "-munsafe-fp-atomics", "-ffp-contract=fast"]
 
+# per-file extra flags: SLP-packing the fp32 time-stepping loop into v_pk_* is an anti-lever on gfx950
+# (a v_pk_fma_f32 is no faster than two v_fma_f32 and blocks DPP folding)
+EXTRA_FLAGS = {"ddh.hip": ["-fno-slp-vectorize"]}
+
 # host sources that contain device code (device lambdas) and must be compiled as HIP
 HIP_HOST_SOURCES = {"capi.cpp"}
 
@@ -55,6 +59,7 @@ def _compile(src: Path, as_hip: bool, headers_mtime: float, verbose: bool) -> Pa
     cmd = [hipcc(), *COMMON, *[f"-I{p}" for p in INCLUDES]]
     if as_hip:
         cmd += HIP_FLAGS
+    cmd += EXTRA_FLAGS.get(src.name, [])
     cmd += ["-c", str(src), "-o", str(obj)]
     if verbose:
         print(" ".join(cmd), flush=True)

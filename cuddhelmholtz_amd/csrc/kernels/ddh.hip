@@ -24,7 +24,7 @@ struct cuddh_ddh_plan
 {
     cuddh_ddh_desc d;
     int is_f64;
-    int kernel; // 1 block, 2 wave
+    int kernel; // 1 block, 2 wave, 3 wave with hand-folded DPP FMAs (fp32)
     int nodes;  // nb*nb*nel1d*nel1d
 };
 
@@ -66,7 +66,79 @@ namespace
     constexpr int ROW_SHR1 = 0x111;                      // lane j reads lane j-1
 
     // ---------------------------------------------------------------- wavefront-per-subdomain kernel (NB = 4, 4x4 elements)
+
+    // out[l] = sum_i c[i] * (value of in[l] in lane i of my quad), l = 0..3.
+    // Generic form: the compiler emits v_mov_b32_dpp + FMA pairs.
     template <typename Real>
+    __device__ inline void quad_contract(const Real (&in)[4], const Real (&c)[4], Real (&out)[4])
+    {
+#pragma unroll
+        for (int l = 0; l < 4; ++l)
+        {
+            Real s = c[0] * dpp_read<QUAD_BCAST(0)>(in[l]);
+            s += c[1] * dpp_read<QUAD_BCAST(1)>(in[l]);
+            s += c[2] * dpp_read<QUAD_BCAST(2)>(in[l]);
+            s += c[3] * dpp_read<QUAD_BCAST(3)>(in[l]);
+            out[l] = s;
+        }
+    }
+
+    // fp32 form with the cross-lane read folded into the FMA (v_fmac_f32_dpp): 16 VALU instructions
+    // instead of 32.  hipcc does not fold a DPP move into an accumulating FMA by itself.  The leading
+    // s_nop covers the "VALU write -> DPP read" hazard (2 wait states) for the inputs; inside the block
+    // DPP operands are only the (unmodified) inputs.
+#define CUDDH_QP(i) " quad_perm:[" #i "," #i "," #i "," #i "] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+    __device__ inline void quad_contract_asm(const float (&in)[4], const float (&c)[4], float (&out)[4])
+    {
+        float o0, o1, o2, o3;
+        asm volatile("s_nop 1\n\t"
+                     "v_mul_f32_dpp %0, %4, %8" CUDDH_QP(0)
+                     "v_mul_f32_dpp %1, %5, %8" CUDDH_QP(0)
+                     "v_mul_f32_dpp %2, %6, %8" CUDDH_QP(0)
+                     "v_mul_f32_dpp %3, %7, %8" CUDDH_QP(0)
+                     "v_fmac_f32_dpp %0, %4, %9" CUDDH_QP(1)
+                     "v_fmac_f32_dpp %1, %5, %9" CUDDH_QP(1)
+                     "v_fmac_f32_dpp %2, %6, %9" CUDDH_QP(1)
+                     "v_fmac_f32_dpp %3, %7, %9" CUDDH_QP(1)
+                     "v_fmac_f32_dpp %0, %4, %10" CUDDH_QP(2)
+                     "v_fmac_f32_dpp %1, %5, %10" CUDDH_QP(2)
+                     "v_fmac_f32_dpp %2, %6, %10" CUDDH_QP(2)
+                     "v_fmac_f32_dpp %3, %7, %10" CUDDH_QP(2)
+                     "v_fmac_f32_dpp %0, %4, %11" CUDDH_QP(3)
+                     "v_fmac_f32_dpp %1, %5, %11" CUDDH_QP(3)
+                     "v_fmac_f32_dpp %2, %6, %11" CUDDH_QP(3)
+                     "v_fmac_f32_dpp %3, %7, %11" CUDDH_QP(3)
+                     : "=&v"(o0), "=&v"(o1), "=&v"(o2), "=&v"(o3)
+                     : "v"(in[0]), "v"(in[1]), "v"(in[2]), "v"(in[3]), "v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]));
+        out[0] = o0;
+        out[1] = o1;
+        out[2] = o2;
+        out[3] = o3;
+    }
+
+    // r[l] = mR * (z[l] of lane+1) + mL * (z[l] of lane-1) within the 16-lane row, fp32, 8 instructions
+    __device__ inline void row_neighbours_asm(const float (&z)[4], float mR, float mL, float (&r)[4])
+    {
+        float o0, o1, o2, o3;
+        asm volatile("s_nop 1\n\t"
+                     "v_mul_f32_dpp %0, %4, %8 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                     "v_mul_f32_dpp %1, %5, %8 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                     "v_mul_f32_dpp %2, %6, %8 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                     "v_mul_f32_dpp %3, %7, %8 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                     "v_fmac_f32_dpp %0, %4, %9 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                     "v_fmac_f32_dpp %1, %5, %9 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                     "v_fmac_f32_dpp %2, %6, %9 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                     "v_fmac_f32_dpp %3, %7, %9 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                     : "=&v"(o0), "=&v"(o1), "=&v"(o2), "=&v"(o3)
+                     : "v"(z[0]), "v"(z[1]), "v"(z[2]), "v"(z[3]), "v"(mR), "v"(mL));
+        r[0] = o0;
+        r[1] = o1;
+        r[2] = o2;
+        r[3] = o3;
+    }
+#undef CUDDH_QP
+
+    template <bool ASM, typename Real>
     __device__ inline void wave_stiffness(const Real (&w)[4], Real (&z)[4], const Real (&gx)[4], const Real (&gy)[4], const Real (&gz)[4],
                                           const Real (&Dk)[4], const Real (&DTk)[4], const Real *__restrict__ Dm, Real mR, Real mL,
                                           Real mU, Real mD, int lane)
@@ -83,15 +155,10 @@ namespace
             uy[l] = s;
         }
         // xi derivative: u(i, l) sits in lane i of my quad
-#pragma unroll
-        for (int l = 0; l < 4; ++l)
-        {
-            Real s = Dk[0] * dpp_read<QUAD_BCAST(0)>(w[l]);
-            s += Dk[1] * dpp_read<QUAD_BCAST(1)>(w[l]);
-            s += Dk[2] * dpp_read<QUAD_BCAST(2)>(w[l]);
-            s += Dk[3] * dpp_read<QUAD_BCAST(3)>(w[l]);
-            ux[l] = s;
-        }
+        if constexpr (ASM)
+            quad_contract_asm(w, Dk, ux);
+        else
+            quad_contract(w, Dk, ux);
         Real f1[4], f2[4];
 #pragma unroll
         for (int l = 0; l < 4; ++l)
@@ -100,25 +167,38 @@ namespace
             f2[l] = gy[l] * ux[l] + gz[l] * uy[l];
         }
         // test functions: sum_i D(i,k) f1(i,l)  +  sum_i D(i,l) f2(k,i)
+        Real zz[4];
+        if constexpr (ASM)
+            quad_contract_asm(f1, DTk, zz);
+        else
+            quad_contract(f1, DTk, zz);
 #pragma unroll
         for (int l = 0; l < 4; ++l)
         {
-            Real s = DTk[0] * dpp_read<QUAD_BCAST(0)>(f1[l]);
-            s += DTk[1] * dpp_read<QUAD_BCAST(1)>(f1[l]);
-            s += DTk[2] * dpp_read<QUAD_BCAST(2)>(f1[l]);
-            s += DTk[3] * dpp_read<QUAD_BCAST(3)>(f1[l]);
+            Real s = zz[l];
 #pragma unroll
             for (int i = 0; i < 4; ++i)
                 s += Dm[i + 4 * l] * f2[i];
-            z[l] = s;
+            zz[l] = s;
         }
         // assembly across elements.  xi neighbours: my k==3 column meets the k==0 column of lane+1 (and vice versa)
-#pragma unroll
-        for (int l = 0; l < 4; ++l)
+        if constexpr (ASM)
         {
-            const Real from_right = dpp_read<ROW_SHL1>(z[l]);
-            const Real from_left = dpp_read<ROW_SHR1>(z[l]);
-            z[l] = (z[l] + mR * from_right) + mL * from_left;
+            Real r[4];
+            row_neighbours_asm(zz, mR, mL, r);
+#pragma unroll
+            for (int l = 0; l < 4; ++l)
+                z[l] = zz[l] + r[l];
+        }
+        else
+        {
+#pragma unroll
+            for (int l = 0; l < 4; ++l)
+            {
+                const Real from_right = dpp_read<ROW_SHL1>(zz[l]);
+                const Real from_left = dpp_read<ROW_SHR1>(zz[l]);
+                z[l] = zz[l] + (mR * from_right + mL * from_left);
+            }
         }
         // eta neighbours: my l==3 node meets the l==0 node of lane+16 (and vice versa)
         {
@@ -130,7 +210,7 @@ namespace
         }
     }
 
-    template <typename Real>
+    template <typename Real, bool ASM>
     __global__ void __launch_bounds__(256) ddh_wave_kernel(DdhArgs<Real> A, const Real *__restrict__ Dmat, const Real *__restrict__ filt,
                                                           const Real *__restrict__ cs, const Real *__restrict__ sn)
     {
@@ -219,7 +299,7 @@ namespace
                 const Real kw = filt[it];
                 Real z[4], ph[4], qh[4];
 
-                wave_stiffness(p, z, gx, gy, gz, Dk, DTk, Dmat, mR, mL, mU, mD, lane);
+                wave_stiffness<ASM>(p, z, gx, gy, gz, Dk, DTk, Dmat, mR, mL, mU, mD, lane);
 #pragma unroll
                 for (int l = 0; l < 4; ++l)
                 {
@@ -228,7 +308,7 @@ namespace
                     qh[l] = q[l] + half_dt * dq;
                     p[l] -= dt * qh[l];
                 }
-                wave_stiffness(ph, z, gx, gy, gz, Dk, DTk, Dmat, mR, mL, mU, mD, lane);
+                wave_stiffness<ASM>(ph, z, gx, gy, gz, Dk, DTk, Dmat, mR, mL, mU, mD, lane);
 #pragma unroll
                 for (int l = 0; l < 4; ++l)
                 {
@@ -574,10 +654,18 @@ namespace
         A.lambda = lambda;
         A.update = update;
 
-        if (plan->kernel == 2)
+        if (plan->kernel == 2 || plan->kernel == 3)
         {
-            hipLaunchKernelGGL((ddh_wave_kernel<Real>), dim3((n_local + 3) / 4), dim3(256), 0, st, A, static_cast<const Real *>(d.D),
-                               static_cast<const Real *>(d.wh_filter), static_cast<const Real *>(d.cs), static_cast<const Real *>(d.sn));
+            // kernel 3 (hand-folded DPP FMAs) exists in fp32 only; fp64 always takes the generic form
+            constexpr bool can_asm = sizeof(Real) == 4;
+            if (can_asm && plan->kernel == 3)
+                hipLaunchKernelGGL((ddh_wave_kernel<Real, can_asm>), dim3((n_local + 3) / 4), dim3(256), 0, st, A,
+                                   static_cast<const Real *>(d.D), static_cast<const Real *>(d.wh_filter),
+                                   static_cast<const Real *>(d.cs), static_cast<const Real *>(d.sn));
+            else
+                hipLaunchKernelGGL((ddh_wave_kernel<Real, false>), dim3((n_local + 3) / 4), dim3(256), 0, st, A,
+                                   static_cast<const Real *>(d.D), static_cast<const Real *>(d.wh_filter),
+                                   static_cast<const Real *>(d.cs), static_cast<const Real *>(d.sn));
             return launch_status();
         }
 
@@ -630,7 +718,7 @@ extern "C"
         p->kernel = 1;
 
         const bool wave_shape = (desc->nb == 4 && desc->nel1d == 4);
-        if (kernel == 2 && !wave_shape)
+        if ((kernel == 2 || kernel == 3) && !wave_shape)
         {
             delete p;
             return static_cast<int>(hipErrorInvalidValue);
@@ -656,8 +744,8 @@ extern "C"
                 return static_cast<int>(e);
             }
             if (!bad)
-                p->kernel = 2;
-            else if (kernel == 2)
+                p->kernel = (kernel == 2) ? 2 : 3; // auto prefers the folded-DPP form (fp64 runs the generic form either way)
+            else if (kernel == 2 || kernel == 3)
             {
                 delete p;
                 return static_cast<int>(hipErrorInvalidValue);

@@ -96,7 +96,7 @@ int cuddh_nodal_values(void *fem, int integrand, double param, double *out);
 
 /* ---- DDH (reference include/DDH.hpp) */
 /* h_a HOST nodal coefficient; f64 != 0 selects the fp64 parity variant (double traces);
- * kernel: 0 auto, 1 workgroup-per-subdomain, 2 wavefront-per-subdomain */
+ * kernel: 0 auto, 1 workgroup-per-subdomain, 2 wavefront-per-subdomain, 3 wavefront with DPP-folded FMAs */
 void *cuddh_ddh_create(double omega, const double *h_a, void *fem, int nx, int ny, int f64, int kernel);
 void cuddh_ddh_destroy(void *ddh);
 int cuddh_ddh_size(void *ddh);

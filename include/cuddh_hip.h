@@ -186,10 +186,11 @@ typedef struct cuddh_ddh_plan cuddh_ddh_plan;
  * source/DDH.cpp:108; structure check for the wave-per-subdomain kernel).
  * Allocates and synchronises.  is_f64 selects the arithmetic type of `desc`.
  * kernel: 0 = auto, 1 = generic (one workgroup per subdomain, LDS),
- *         2 = wave (one wavefront per subdomain, registers + DPP; nb == 4 only). */
+ *         2 = wave (one wavefront per subdomain, registers + DPP; nb == 4 only),
+ *         3 = wave with the DPP reads folded into the FMAs by hand (fp32; what auto picks when it applies). */
 int cuddh_hip_ddh_plan_create(cuddh_ddh_plan **plan, const cuddh_ddh_desc *desc, int is_f64, int kernel);
 int cuddh_hip_ddh_plan_destroy(cuddh_ddh_plan *plan);
-/* which kernel the plan resolved to (1 or 2) */
+/* which kernel the plan resolved to (1, 2 or 3) */
 int cuddh_hip_ddh_plan_kernel(const cuddh_ddh_plan *plan);
 
 /* source/DDH.cpp:111-321 (ddh_action + stiffness).  x: forcing [F;G] (2*g_ndof

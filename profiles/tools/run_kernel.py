@@ -1,0 +1,37 @@
+"""Runs one hot kernel a few times (for rocprofv3 counter passes).
+usage: run_kernel.py helm|ddh NX [REPS] [KERNEL]"""
+import math
+import sys
+from pathlib import Path
+
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[2]))
+import cuddhelmholtz_amd as cd  # noqa: E402
+
+which, nx = sys.argv[1], int(sys.argv[2])
+reps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+kernel = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+dev = torch.device("cuda:0")
+cd.use_torch_stream()
+omega = math.pi * nx / 32.0
+mesh = cd.Mesh2D.uniform_rect(nx, -1.0, 1.0, nx, -1.0, 1.0)
+fem = cd.H1Space(mesh, cd.Basis(4))
+ndof = fem.size()
+if which == "helm":
+    fs = cd.FaceSpace(fem, mesh.boundary_edges())
+    A = cd.HelmholtzOperator(omega, torch.ones(ndof, dtype=torch.float64, device=dev), torch.ones(fs.size(), dtype=torch.float64, device=dev), fem, fs)
+    x = torch.rand(2 * ndof, dtype=torch.float64, device=dev)
+    y = torch.empty_like(x)
+    for _ in range(reps):
+        A.action(x, y)
+else:
+    import numpy as np
+
+    F = cd.DDH(omega, np.ones(ndof), fem, nx, nx, kernel=kernel)
+    lam = torch.rand(F.size(), dtype=torch.float32, device=dev)
+    out = torch.zeros_like(lam)
+    for _ in range(reps):
+        F.action(lam, out)
+torch.cuda.synchronize()
+print("done", which, nx, reps)

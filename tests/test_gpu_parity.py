@@ -356,7 +356,7 @@ def test_ddh_fp64_entry_points(cuda, nx, nb, kernel):
     assert torch.equal(upd, full)
 
 
-@pytest.mark.parametrize("nx,nb,kernel", [(8, 4, 1), (8, 4, 2), (16, 4, 2), (8, 8, 1)])
+@pytest.mark.parametrize("nx,nb,kernel", [(8, 4, 1), (8, 4, 2), (8, 4, 3), (16, 4, 2), (16, 4, 3), (8, 8, 1)])
 def test_ddh_fp32_reference_precision(cuda, nx, nb, kernel):
     import torch
 
@@ -365,6 +365,7 @@ def test_ddh_fp32_reference_precision(cuda, nx, nb, kernel):
     omega, d, h_a, fh = ddh_case(nx, nb)
     fem = cd.H1Space(cd.Mesh2D.uniform_rect(nx, -1.0, 1.0, nx, -1.0, 1.0), cd.Basis(nb))
     F = cd.DDH(omega, h_a, fem, nx, nx, precision="f32", kernel=kernel)
+    assert F.info()["kernel"] == kernel
     O64 = oracle.DDH(d, nx, nx, omega, h_a, np.float64)
     O32 = oracle.DDH(d, nx, nx, omega, h_a, np.float32)
     f = to_dev(torch, fh, cuda)
