@@ -12,13 +12,15 @@
 //     the 1-D interpolation/differentiation matrices are compile-time-indexed
 //     loads from a uniform pointer (scalar registers);
 //   * metric arrays are stored patch-major, structure-of-arrays
-//     [patch][component][point][32 lanes]: every load instruction reads 256
-//     contiguous bytes;
+//     [patch][xi-slice q][component][eta index r][32 lanes]: every load instruction
+//     reads 256 contiguous bytes and the 3*nq (or nq) loads of one slice cover one
+//     contiguous 3.75 KB (2 KB) block, so DRAM pages are read whole;
 //   * dofs owned by one patch are stored straight to y; dofs on patch borders go
 //     to per-patch slots that a second small kernel sums in a fixed order.
 // The apply is therefore bitwise reproducible and needs no zero-fill of y.
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -35,10 +37,10 @@ struct cuddh_helmholtz_plan
     int *dof_list = nullptr;  // global dof of every patch-local dof
     int *slot_of = nullptr;   // -1: the patch owns the dof, else its slot in `part`
     int *patch_nel = nullptr; // elements in the patch (32 except possibly the last)
-    uint16_t *lidx = nullptr; // [n_patches][nb*nb][32] element node -> patch-local dof
+    uint32_t *lidx = nullptr; // [n_patches][ceil(nb*nb/2)][32]: element nodes 2j, 2j+1 -> patch-local dofs, packed lo | hi << 16
     uint8_t *colour = nullptr; // [n_patches][32]
-    double *Gp = nullptr;     // [n_patches][3][nqS*nqS][32]
-    double *aMp = nullptr;    // [n_patches][nqM*nqM][32]
+    double *Gp = nullptr;     // [n_patches][q: nqS][3][r: nqS][32]  (point (q,r) = xi index q, eta index r)
+    double *aMp = nullptr;    // [n_patches][q: nqM][r: nqM][32]
     // faces, grouped by patch
     int *face_off = nullptr;       // [n_patches + 1]
     uint16_t *face_lidx = nullptr; // [n_faces_total][nb]
@@ -51,6 +53,7 @@ struct cuddh_helmholtz_plan
     int *shared_dof = nullptr, *shared_off = nullptr, *shared_slots = nullptr;
     double *part = nullptr; // [2][n_slots]
     size_t bytes_alg = 0, bytes_actual = 0;
+    int prefetch = 0; // kernel variant (tuning knob, env CUDDH_HELM_PREFETCH)
 };
 
 namespace
@@ -62,15 +65,18 @@ namespace
         int ndof, max_loc, ncol, nfcol, nqF, n_slots;
         double omega;
         const int *dof_off, *dof_list, *slot_of, *patch_nel, *face_off, *face_id;
-        const uint16_t *lidx, *face_lidx;
+        const uint32_t *lidx;
+        const uint16_t *face_lidx;
         const uint8_t *colour, *face_col;
         const double *Gp, *aMp, *aF;
         const double *x;
         double *y, *part;
     };
 
-    template <int NB, int NQS, int NQM>
-    __global__ void __launch_bounds__(64, (NB >= 5 ? 2 : 4)) helm_patch_kernel(HelmArgs A, const double *__restrict__ PS, const double *__restrict__ DS,
+    // MODE: how the metric slices reach the registers -- 0 load-then-use, 1 software pipelined (second register set),
+    // 2 split between the two half-waves and exchanged with ds_bpermute (see the element phase)
+    template <int NB, int NQS, int NQM, int MODE>
+    __global__ void __launch_bounds__(64, (NB >= 5 ? 2 : (MODE >= 1 ? 3 : 4))) helm_patch_kernel(HelmArgs A, const double *__restrict__ PS, const double *__restrict__ DS,
                                                            const double *__restrict__ PM, const double *__restrict__ PF)
     {
         constexpr int NN = NB * NB;
@@ -85,119 +91,244 @@ namespace
         const int nloc = A.dof_off[patch + 1] - off;
         const int *dofs = A.dof_list + off;
 
-        for (int i = lane; i < nloc; i += 64)
+        const double *Gp = A.Gp + (size_t)patch * 3 * NQS * NQS * PE + le;
+        const double *ap = A.aMp + (size_t)patch * NQM * NQM * PE + le;
+
+        // gather x of the patch's dofs into LDS: indices first, then values, four 64-lane rows at a time, so that
+        // each wave has 4 + 8 loads in flight instead of a chain of dependent single loads
+        for (int base = 0; base < nloc; base += 256)
         {
-            const int g = dofs[i];
-            xs[i] = A.x[g];
-            xs[ML + i] = A.x[A.ndof + g];
-            ys[i] = 0.0;
-            ys[ML + i] = 0.0;
+            int gi[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                gi[j] = dofs[min(base + 64 * j + lane, nloc - 1)];
+            double xu[4], xv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+            {
+                xu[j] = A.x[gi[j]];
+                xv[j] = A.x[A.ndof + gi[j]];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+            {
+                const int i = base + 64 * j + lane;
+                if (i < nloc)
+                {
+                    xs[i] = xu[j];
+                    xs[ML + i] = xv[j];
+                    ys[i] = 0.0;
+                    ys[ML + i] = 0.0;
+                }
+            }
         }
         __syncthreads();
 
         // ------------------------------------------------------------ element phase
         const bool active = le < A.patch_nel[patch];
-        const uint16_t *li = A.lidx + ((size_t)patch * NN) * PE + le;
+        constexpr int NP = (NN + 1) / 2;
+        const uint32_t *li = A.lidx + ((size_t)patch * NP) * PE + le;
         const double *xc = xs + comp * ML;
 
+        // element node -> patch-local dof, two 16-bit indices per register, kept for the gather here and the
+        // scatter below (lidx is padded to 32 lanes per patch, so inactive lanes read valid zeros)
+        uint32_t lpk[NP];
+#pragma unroll
+        for (int j = 0; j < NP; ++j)
+            lpk[j] = li[j * PE];
+        auto lix_of = [&](int n) -> int { return (n & 1) ? static_cast<int>(lpk[n >> 1] >> 16) : static_cast<int>(lpk[n >> 1] & 0xFFFFu); };
+        const double keep = active ? 1.0 : 0.0;
         double u[NN], out[NN];
 #pragma unroll
         for (int n = 0; n < NN; ++n)
         {
-            u[n] = active ? xc[li[n * PE]] : 0.0;
+            u[n] = keep * xc[lix_of(n)];
             out[n] = 0.0;
         }
 
+        // One quadrature "slice" = all points with the same xi index q.
         // stiffness: out(k,l) += sum_q [ D(q,k) sum_r P(r,l) F0(q,r) + P(q,k) sum_r D(r,l) F1(q,r) ]
+        auto load_stiff = [&](int q, double (&g)[3 * NQS])
         {
-            const double *Gp = A.Gp + (size_t)patch * 3 * NQS * NQS * PE + le;
-            // q stays a real loop: one iteration keeps 3*NQS metric loads in flight, which is enough to cover the
-            // HBM latency; unrolling it lets the scheduler hoist every load of the element and exhausts the VGPRs
+#pragma unroll
+            for (int r = 0; r < NQS; ++r)
+            {
+                g[3 * r + 0] = Gp[((q * 3 + 0) * NQS + r) * PE];
+                g[3 * r + 1] = Gp[((q * 3 + 1) * NQS + r) * PE];
+                g[3 * r + 2] = Gp[((q * 3 + 2) * NQS + r) * PE];
+            }
+        };
+        auto stiff_slice = [&](int q, const double (&g)[3 * NQS])
+        {
+            double pu[NB], du[NB], t0[NB], t1[NB];
+#pragma unroll
+            for (int l = 0; l < NB; ++l)
+            {
+                double a = 0.0, b = 0.0;
+#pragma unroll
+                for (int k = 0; k < NB; ++k)
+                {
+                    a += PS[q + NQS * k] * u[k + NB * l];
+                    b += DS[q + NQS * k] * u[k + NB * l];
+                }
+                pu[l] = a;
+                du[l] = b;
+                t0[l] = 0.0;
+                t1[l] = 0.0;
+            }
+#pragma unroll
+            for (int r = 0; r < NQS; ++r)
+            {
+                const double ga = g[3 * r + 0], gb = g[3 * r + 1], gc = g[3 * r + 2];
+                double dx = 0.0, dy = 0.0;
+#pragma unroll
+                for (int l = 0; l < NB; ++l)
+                {
+                    dx += PS[r + NQS * l] * du[l];
+                    dy += DS[r + NQS * l] * pu[l];
+                }
+                const double f0 = ga * dx + gb * dy;
+                const double f1 = gb * dx + gc * dy;
+#pragma unroll
+                for (int l = 0; l < NB; ++l)
+                {
+                    t0[l] += PS[r + NQS * l] * f0;
+                    t1[l] += DS[r + NQS * l] * f1;
+                }
+            }
+#pragma unroll
+            for (int l = 0; l < NB; ++l)
+#pragma unroll
+                for (int k = 0; k < NB; ++k)
+                    out[k + NB * l] += DS[q + NQS * k] * t0[l] + PS[q + NQS * k] * t1[l];
+        };
+
+        // mass: out(k,l) += -w^2 sum_q P(q,k) sum_r P(r,l) a(q,r) (sum_{k'l'} P(q,k') P(r,l') u(k',l'))
+        const double w2 = -A.omega * A.omega;
+        auto load_mass = [&](int q, double (&a)[NQM])
+        {
+#pragma unroll
+            for (int r = 0; r < NQM; ++r)
+                a[r] = ap[(q * NQM + r) * PE];
+        };
+        auto mass_slice = [&](int q, const double (&am)[NQM])
+        {
+            double pu[NB], t[NB];
+#pragma unroll
+            for (int l = 0; l < NB; ++l)
+            {
+                double a = 0.0;
+#pragma unroll
+                for (int k = 0; k < NB; ++k)
+                    a += PM[q + NQM * k] * u[k + NB * l];
+                pu[l] = a;
+                t[l] = 0.0;
+            }
+#pragma unroll
+            for (int r = 0; r < NQM; ++r)
+            {
+                double val = 0.0;
+#pragma unroll
+                for (int l = 0; l < NB; ++l)
+                    val += PM[r + NQM * l] * pu[l];
+                val *= am[r] * w2;
+#pragma unroll
+                for (int l = 0; l < NB; ++l)
+                    t[l] += PM[r + NQM * l] * val;
+            }
+#pragma unroll
+            for (int l = 0; l < NB; ++l)
+#pragma unroll
+                for (int k = 0; k < NB; ++k)
+                    out[k + NB * l] += PM[q + NQM * k] * t[l];
+        };
+
+        if constexpr (MODE == 2)
+        {
+            // The two half-waves (u lanes / v lanes) need the same metric values.  Instead of both fetching the same
+            // slice, the lower half fetches slice 2j and the upper half slice 2j+1, and each value is handed to the
+            // other half with ds_bpermute when its slice is processed: twice the bytes in flight per register.
+#pragma unroll 1
+            for (int qp = 0; qp < (NQS + 1) / 2; ++qp)
+            {
+                const int q0 = 2 * qp, q1 = (2 * qp + 1 < NQS) ? 2 * qp + 1 : q0;
+                double R[3 * NQS], g[3 * NQS];
+                load_stiff(comp ? q1 : q0, R);
+#pragma unroll
+                for (int j = 0; j < 3 * NQS; ++j)
+                    g[j] = __shfl(R[j], le, 64);
+                stiff_slice(q0, g);
+                if (2 * qp + 1 < NQS)
+                {
+#pragma unroll
+                    for (int j = 0; j < 3 * NQS; ++j)
+                        g[j] = __shfl(R[j], le + 32, 64);
+                    stiff_slice(q1, g);
+                }
+            }
+#pragma unroll 1
+            for (int qp = 0; qp < (NQM + 1) / 2; ++qp)
+            {
+                const int q0 = 2 * qp, q1 = (2 * qp + 1 < NQM) ? 2 * qp + 1 : q0;
+                double R[NQM], am[NQM];
+                load_mass(comp ? q1 : q0, R);
+#pragma unroll
+                for (int j = 0; j < NQM; ++j)
+                    am[j] = __shfl(R[j], le, 64);
+                mass_slice(q0, am);
+                if (2 * qp + 1 < NQM)
+                {
+#pragma unroll
+                    for (int j = 0; j < NQM; ++j)
+                        am[j] = __shfl(R[j], le + 32, 64);
+                    mass_slice(q1, am);
+                }
+            }
+        }
+        else if constexpr (MODE == 1)
+        {
+            // slice q+1 is requested before slice q is consumed (second register set, one wave per SIMD fewer)
+            double gcur[3 * NQS];
+            load_stiff(0, gcur);
 #pragma unroll 1
             for (int q = 0; q < NQS; ++q)
             {
-                double pu[NB], du[NB], t0[NB], t1[NB];
+                double gnext[3 * NQS];
+                load_stiff((q + 1 < NQS) ? q + 1 : q, gnext); // the last iteration re-requests its own slice: a cache hit
+                stiff_slice(q, gcur);
 #pragma unroll
-                for (int l = 0; l < NB; ++l)
-                {
-                    double a = 0.0, b = 0.0;
-#pragma unroll
-                    for (int k = 0; k < NB; ++k)
-                    {
-                        a += PS[q + NQS * k] * u[k + NB * l];
-                        b += DS[q + NQS * k] * u[k + NB * l];
-                    }
-                    pu[l] = a;
-                    du[l] = b;
-                    t0[l] = 0.0;
-                    t1[l] = 0.0;
-                }
-#pragma unroll
-                for (int r = 0; r < NQS; ++r)
-                {
-                    const int pt = q + NQS * r;
-                    const double ga = Gp[(0 * NQS * NQS + pt) * PE];
-                    const double gb = Gp[(1 * NQS * NQS + pt) * PE];
-                    const double gc = Gp[(2 * NQS * NQS + pt) * PE];
-                    double dx = 0.0, dy = 0.0;
-#pragma unroll
-                    for (int l = 0; l < NB; ++l)
-                    {
-                        dx += PS[r + NQS * l] * du[l];
-                        dy += DS[r + NQS * l] * pu[l];
-                    }
-                    const double f0 = ga * dx + gb * dy;
-                    const double f1 = gb * dx + gc * dy;
-#pragma unroll
-                    for (int l = 0; l < NB; ++l)
-                    {
-                        t0[l] += PS[r + NQS * l] * f0;
-                        t1[l] += DS[r + NQS * l] * f1;
-                    }
-                }
-#pragma unroll
-                for (int l = 0; l < NB; ++l)
-#pragma unroll
-                    for (int k = 0; k < NB; ++k)
-                        out[k + NB * l] += DS[q + NQS * k] * t0[l] + PS[q + NQS * k] * t1[l];
+                for (int j = 0; j < 3 * NQS; ++j)
+                    gcur[j] = gnext[j];
             }
-        }
-
-        // mass: out(k,l) += -w^2 sum_q P(q,k) sum_r P(r,l) a(q,r) (sum_{k'l'} P(q,k') P(r,l') u(k',l'))
-        {
-            const double *ap = A.aMp + (size_t)patch * NQM * NQM * PE + le;
-            const double w2 = -A.omega * A.omega;
+            double acur[NQM];
+            load_mass(0, acur);
 #pragma unroll 1
             for (int q = 0; q < NQM; ++q)
             {
-                double pu[NB], t[NB];
+                double anext[NQM];
+                load_mass((q + 1 < NQM) ? q + 1 : q, anext);
+                mass_slice(q, acur);
 #pragma unroll
-                for (int l = 0; l < NB; ++l)
-                {
-                    double a = 0.0;
-#pragma unroll
-                    for (int k = 0; k < NB; ++k)
-                        a += PM[q + NQM * k] * u[k + NB * l];
-                    pu[l] = a;
-                    t[l] = 0.0;
-                }
-#pragma unroll
-                for (int r = 0; r < NQM; ++r)
-                {
-                    double val = 0.0;
-#pragma unroll
-                    for (int l = 0; l < NB; ++l)
-                        val += PM[r + NQM * l] * pu[l];
-                    val *= ap[(q + NQM * r) * PE] * w2;
-#pragma unroll
-                    for (int l = 0; l < NB; ++l)
-                        t[l] += PM[r + NQM * l] * val;
-                }
-#pragma unroll
-                for (int l = 0; l < NB; ++l)
-#pragma unroll
-                    for (int k = 0; k < NB; ++k)
-                        out[k + NB * l] += PM[q + NQM * k] * t[l];
+                for (int j = 0; j < NQM; ++j)
+                    acur[j] = anext[j];
+            }
+        }
+        else
+        {
+            // q stays a real loop: unrolling it lets the scheduler hoist every load of the element and exhausts the VGPRs
+#pragma unroll 1
+            for (int q = 0; q < NQS; ++q)
+            {
+                double g[3 * NQS];
+                load_stiff(q, g);
+                stiff_slice(q, g);
+            }
+#pragma unroll 1
+            for (int q = 0; q < NQM; ++q)
+            {
+                double am[NQM];
+                load_mass(q, am);
+                mass_slice(q, am);
             }
         }
 
@@ -212,7 +343,7 @@ namespace
                 {
 #pragma unroll
                     for (int n = 0; n < NN; ++n)
-                        yc[li[n * PE]] += sgn * out[n];
+                        yc[lix_of(n)] += sgn * out[n];
                 }
                 __syncthreads();
             }
@@ -276,19 +407,32 @@ namespace
 
         // ------------------------------------------------------------ write out
         const int *slot = A.slot_of + off;
-        for (int i = lane; i < nloc; i += 64)
+        for (int base = 0; base < nloc; base += 256)
         {
-            const int s = slot[i];
-            if (s < 0)
+            int si[4], gi[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
             {
-                const int g = dofs[i];
-                A.y[g] = ys[i];
-                A.y[A.ndof + g] = ys[ML + i];
+                const int i = min(base + 64 * j + lane, nloc - 1);
+                si[j] = slot[i];
+                gi[j] = dofs[i];
             }
-            else
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
             {
-                A.part[s] = ys[i];
-                A.part[A.n_slots + s] = ys[ML + i];
+                const int i = base + 64 * j + lane;
+                if (i >= nloc)
+                    continue;
+                if (si[j] < 0)
+                {
+                    A.y[gi[j]] = ys[i];
+                    A.y[A.ndof + gi[j]] = ys[ML + i];
+                }
+                else
+                {
+                    A.part[si[j]] = ys[i];
+                    A.part[A.n_slots + si[j]] = ys[ML + i];
+                }
             }
         }
     }
@@ -312,20 +456,22 @@ namespace
         }
     }
 
-    // reference layout (c, pt, el) -> [patch][c][pt][32]
-    __global__ void __launch_bounds__(256) repack_kernel(long long total, int comps, int npts, const int *__restrict__ perm,
+    // reference layout (c, q, r, el) -> [patch][q][c][r][32]
+    __global__ void __launch_bounds__(256) repack_kernel(long long total, int comps, int nq, const int *__restrict__ perm,
                                                         const double *__restrict__ src, double *__restrict__ dst)
     {
         for (long long t = blockIdx.x * 256LL + threadIdx.x; t < total; t += gridDim.x * 256LL)
         {
             const int le = static_cast<int>(t % PE);
-            long long r = t / PE;
-            const int pt = static_cast<int>(r % npts);
-            r /= npts;
-            const int c = static_cast<int>(r % comps);
-            const long long patch = r / comps;
+            long long rest = t / PE;
+            const int r = static_cast<int>(rest % nq);
+            rest /= nq;
+            const int c = static_cast<int>(rest % comps);
+            rest /= comps;
+            const int q = static_cast<int>(rest % nq);
+            const long long patch = rest / nq;
             const int el = perm[patch * PE + le];
-            dst[t] = el >= 0 ? src[c + (size_t)comps * (pt + (size_t)npts * el)] : 0.0;
+            dst[t] = el >= 0 ? src[c + (size_t)comps * ((q + (size_t)nq * r) + (size_t)nq * nq * el)] : 0.0;
         }
     }
 
@@ -361,7 +507,12 @@ namespace
     void launch_patch(const cuddh_helmholtz_plan *p, const HelmArgs &A, hipStream_t st)
     {
         const size_t lds = (size_t)4 * p->max_loc * sizeof(double);
-        hipLaunchKernelGGL((helm_patch_kernel<NB, NQS, NQM>), dim3(p->n_patches), dim3(64), lds, st, A, p->PS, p->DS, p->PM, p->PF);
+        if (p->prefetch == 1)
+            hipLaunchKernelGGL((helm_patch_kernel<NB, NQS, NQM, 1>), dim3(p->n_patches), dim3(64), lds, st, A, p->PS, p->DS, p->PM, p->PF);
+        else if (p->prefetch == 2)
+            hipLaunchKernelGGL((helm_patch_kernel<NB, NQS, NQM, 2>), dim3(p->n_patches), dim3(64), lds, st, A, p->PS, p->DS, p->PM, p->PF);
+        else
+            hipLaunchKernelGGL((helm_patch_kernel<NB, NQS, NQM, 0>), dim3(p->n_patches), dim3(64), lds, st, A, p->PS, p->DS, p->PM, p->PF);
     }
 
     bool supported(int nb, int nqS, int nqM)
@@ -405,6 +556,8 @@ extern "C"
         p->nqF = nqF;
         p->n_faces = n_faces;
         p->aF = a_F;
+        if (const char *e = std::getenv("CUDDH_HELM_PREFETCH"))
+            p->prefetch = std::atoi(e);
         const int nn = nb * nb;
 
         // ---- element order: Morton curve over the centroids
@@ -460,7 +613,9 @@ extern "C"
 
         // ---- patch-local numbering, colours
         std::vector<int> dof_off(n_patches + 1, 0), dof_list, patch_nel(n_patches);
-        std::vector<uint16_t> lidx((size_t)n_patches * nn * PE, 0), face_lidx((size_t)n_faces * nb, 0);
+        const int np2 = (nn + 1) / 2;
+        std::vector<uint32_t> lidx((size_t)n_patches * np2 * PE, 0);
+        std::vector<uint16_t> face_lidx((size_t)n_faces * nb, 0);
         std::vector<uint8_t> colour((size_t)n_patches * PE, 0), face_col(n_faces, 0);
         std::vector<int> stamp(ndof, -1), loc(ndof, 0), touches(ndof, 0);
         std::vector<uint32_t> used, usedF;
@@ -488,7 +643,7 @@ extern "C"
                         touches[g]++;
                         used.push_back(0);
                     }
-                    lidx[((size_t)q * nn + n) * PE + le] = static_cast<uint16_t>(loc[g]);
+                    lidx[((size_t)q * np2 + n / 2) * PE + le] |= static_cast<uint32_t>(loc[g]) << (16 * (n & 1));
                     taken |= used[loc[g]];
                 }
                 int c = 0;
@@ -596,8 +751,8 @@ extern "C"
         ok(static_cast<int>(hipMalloc(reinterpret_cast<void **>(&p->aMp), nA * sizeof(double))));
         if (!err)
         {
-            hipLaunchKernelGGL(repack_kernel, dim3(stream_grid(nG, 256)), dim3(256), 0, nullptr, nG, 3, nqS * nqS, d_perm, G_S, p->Gp);
-            hipLaunchKernelGGL(repack_kernel, dim3(stream_grid(nA, 256)), dim3(256), 0, nullptr, nA, 1, nqM * nqM, d_perm, a_M, p->aMp);
+            hipLaunchKernelGGL(repack_kernel, dim3(stream_grid(nG, 256)), dim3(256), 0, nullptr, nG, 3, nqS, d_perm, G_S, p->Gp);
+            hipLaunchKernelGGL(repack_kernel, dim3(stream_grid(nA, 256)), dim3(256), 0, nullptr, nA, 1, nqM, d_perm, a_M, p->aMp);
             ok(launch_status());
             ok(static_cast<int>(hipDeviceSynchronize()));
         }
@@ -614,7 +769,7 @@ extern "C"
         size_t exclusive = 0;
         for (int s : slot_of)
             exclusive += s < 0;
-        p->bytes_actual = (size_t)nG * 8 + (size_t)nA * 8 + lidx.size() * 2 + colour.size() + dof_list.size() * (4 + 4 + 16) +
+        p->bytes_actual = (size_t)nG * 8 + (size_t)nA * 8 + lidx.size() * 4 + colour.size() + dof_list.size() * (4 + 4 + 16) +
                           exclusive * 16 + (size_t)n_slots * (16 + 16 + 4) + (size_t)n_shared * (16 + 8) +
                           (size_t)n_faces * ((size_t)nqF * 8 + (size_t)nb * 2 + 5);
         *out = p;
