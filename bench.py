@@ -103,12 +103,12 @@ def main() -> None:
     info = F.info()
     n = F.size()
     nd = info["n_domains"]
-    d0, d1 = (nd * rank) // world, (nd * (rank + 1)) // world
+    from cuddhelmholtz_amd.dist import ShardedDDH
+
+    sh = ShardedDDH(F, nd, rank, world)  # this rank's contiguous subdomain range + trace-vector all-reduce
 
     b = torch.zeros(n, dtype=torch.float32, device=dev)
-    F.local_traces(d0, d1, f, None, b)  # rhs, sharded
-    if world > 1:
-        dist.all_reduce(b)
+    sh.rhs(f, b)
     torch.cuda.synchronize()
     t_setup = time.time() - t_setup
 
@@ -128,10 +128,7 @@ def main() -> None:
     def arnoldi_step(k: int) -> None:
         vk, vk1 = V[k], V[k + 1]
         # w = (I - T) v_k : local solves of this rank's subdomains, then reassemble the trace vector
-        upd.zero_()
-        F.local_traces(d0, d1, None, vk, upd)
-        if world > 1:
-            dist.all_reduce(upd)
+        sh.traces(None, vk, upd)
         N.check(lib.cuddh_hip_copy_f32(n, p(vk), p(vk1), st))
         N.check(lib.cuddh_hip_axpby_f32(n, -1.0, p(upd), 1.0, p(vk1), st))
         for j in range(k + 1):

@@ -1,0 +1,93 @@
+"""Frozen vectors (tests/golden/hotpath_vectors.npz, made by tests/golden/make_golden.py from the oracle).
+CPU: the oracle still reproduces them.  GPU: the HIP path reproduces them."""
+import math
+
+import numpy as np
+import pytest
+
+import oracle
+from conftest import GOLDEN, load_unstructured_square
+
+G = np.load(GOLDEN / "hotpath_vectors.npz")
+
+
+def rel(a, b):
+    return float(np.linalg.norm(np.asarray(a, dtype=np.float64) - b) / np.linalg.norm(b))
+
+
+def test_oracle_reproduces_golden_helmholtz():
+    xy, elems = load_unstructured_square()
+    for tag, mesh, nb, omega in (("unstructured_nb4", oracle.Mesh(xy, elems), 4, 9.0),
+                                 ("rect12_nb3", oracle.Mesh.uniform_rect(12, -1.0, 1.0, 12, -1.0, 1.0), 3, 5.0)):
+        d = oracle.Discretization(mesh, nb)
+        fs = oracle.FaceSpaceO(d, mesh.boundary_edges)
+        S, M, H = oracle.Stiffness(d), oracle.Mass(d, G[f"{tag}_a2"]), oracle.FaceMass(fs, G[f"{tag}_ax"])
+        x = G[f"{tag}_x"]
+        assert rel(oracle.helmholtz_apply(d, S, M, H, fs, omega, x), G[f"{tag}_Ax"]) < 1e-14
+
+
+def test_oracle_reproduces_golden_ddh():
+    tag = "ddh_8_4"
+    nx, nb = int(G[f"{tag}_meta"][0]), int(G[f"{tag}_meta"][1])
+    omega = float(G[f"{tag}_omega_dt"][0])
+    d = oracle.Discretization(oracle.Mesh.uniform_rect(nx, -1.0, 1.0, nx, -1.0, 1.0), nb)
+    O = oracle.DDH(d, nx, nx, omega, G[f"{tag}_h_a"], np.float64)
+    assert (O.t.n_domains, O.t.n_lambda, O.t.nt) == tuple(int(v) for v in G[f"{tag}_meta"][2:])
+    assert rel(O.rhs(G[f"{tag}_f"]), G[f"{tag}_b"]) < 1e-13
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,kind,nb,omega", [("unstructured_nb4", "unstructured", 4, 9.0), ("rect12_nb3", "rect12", 3, 5.0)])
+def test_gpu_operators_match_golden(cuda, tag, kind, nb, omega):
+    import torch
+
+    import cuddhelmholtz_amd as cd
+
+    if kind == "unstructured":
+        xy, elems = load_unstructured_square()
+        mesh = cd.Mesh2D.from_vertices(xy, elems)
+    else:
+        mesh = cd.Mesh2D.uniform_rect(12, -1.0, 1.0, 12, -1.0, 1.0)
+    fem = cd.H1Space(mesh, cd.Basis(nb))
+    fs = cd.FaceSpace(fem, mesh.boundary_edges())
+    n = fem.size()
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(cuda)  # noqa: E731
+    a2, ax, x = dev(G[f"{tag}_a2"]), dev(G[f"{tag}_ax"]), dev(G[f"{tag}_x"])
+    y = torch.zeros(n, dtype=torch.float64, device=cuda)
+    cd.StiffnessMatrix(fem).action(x[:n], y)
+    assert rel(y.cpu().numpy(), G[f"{tag}_Sx"]) < 1e-12
+    cd.MassMatrix(fem, a2).action(x[:n], y)
+    assert rel(y.cpu().numpy(), G[f"{tag}_Mx"]) < 1e-12
+    yf = torch.zeros(fs.size(), dtype=torch.float64, device=cuda)
+    cd.FaceMassMatrix(fs, ax).action(x[: fs.size()].contiguous(), yf)
+    assert rel(yf.cpu().numpy(), G[f"{tag}_Hx"]) < 1e-12
+    A = cd.HelmholtzOperator(omega, a2, ax, fem, fs)
+    Y = torch.zeros(2 * n, dtype=torch.float64, device=cuda)
+    A.action(x, Y)
+    assert rel(Y.cpu().numpy(), G[f"{tag}_Ax"]) < 1e-12
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,kernel", [("ddh_8_4", 1), ("ddh_8_4", 2), ("ddh_8_4", 3), ("ddh_8_8", 1)])
+def test_gpu_ddh_matches_golden(cuda, tag, kernel):
+    import torch
+
+    import cuddhelmholtz_amd as cd
+
+    nx, nb = int(G[f"{tag}_meta"][0]), int(G[f"{tag}_meta"][1])
+    omega = float(G[f"{tag}_omega_dt"][0])
+    fem = cd.H1Space(cd.Mesh2D.uniform_rect(nx, -1.0, 1.0, nx, -1.0, 1.0), cd.Basis(nb))
+    F = cd.DDH(omega, G[f"{tag}_h_a"], fem, nx, nx, precision="f64", kernel=kernel)
+    info = F.info()
+    assert (info["n_domains"], info["n_lambda"], info["nt"]) == tuple(int(v) for v in G[f"{tag}_meta"][2:])
+    assert abs(info["dt"] - float(G[f"{tag}_omega_dt"][1])) < 1e-18
+    f = torch.from_numpy(G[f"{tag}_f"]).to(cuda)
+    b = torch.zeros(F.size(), dtype=torch.float64, device=cuda)
+    F.rhs(f, b)
+    assert rel(b.cpu().numpy(), G[f"{tag}_b"]) < 1e-10
+    Tb = torch.zeros_like(b)
+    F.local_traces(0, info["n_domains"], None, b, Tb)
+    assert rel(Tb.cpu().numpy(), G[f"{tag}_Tb"]) < 1e-10
+    u = torch.zeros(2 * fem.size(), dtype=torch.float64, device=cuda)
+    F.postprocess(b, f, u)
+    assert rel(u.cpu().numpy(), G[f"{tag}_u"]) < 1e-10

@@ -413,3 +413,34 @@ def test_ddh_gmres_solve_fp64(cuda, kernel):
     assert out.success == info["success"]
     assert abs(out.num_matvec - info["num_matvec"]) <= 1
     assert rel(u.cpu().numpy(), u_ref) < 1e-8
+
+
+def test_sharded_ddh_single_rank_equals_ddh(cuda):
+    """cuddhelmholtz_amd.dist.ShardedDDH with one rank is DDH::action / rhs / postprocess."""
+    import torch
+
+    import cuddhelmholtz_amd as cd
+    from cuddhelmholtz_amd.dist import ShardedDDH
+
+    nx, nb = 16, 4
+    omega, d, h_a, fh = ddh_case(nx, nb)
+    fem = cd.H1Space(cd.Mesh2D.uniform_rect(nx, -1.0, 1.0, nx, -1.0, 1.0), cd.Basis(nb))
+    F = cd.DDH(omega, h_a, fem, nx, nx)
+    sh = ShardedDDH(F, F.info()["n_domains"])
+    f = to_dev(torch, fh, cuda)
+    n = F.size()
+    b1 = torch.zeros(n, dtype=torch.float32, device=cuda)
+    b2 = torch.zeros_like(b1)
+    F.rhs(f, b1)
+    sh.rhs(f, b2)
+    assert torch.equal(b1, b2)
+    y1 = torch.zeros_like(b1)
+    y2 = torch.full_like(b1, 3.0)
+    F.action(b1, y1)
+    sh.action(b1, y2)
+    assert torch.equal(y1, y2)
+    u1 = torch.zeros(2 * d.ndof, dtype=torch.float64, device=cuda)
+    u2 = torch.ones_like(u1)
+    F.postprocess(b1, f, u1)
+    sh.postprocess(b1, f, u2)
+    assert torch.allclose(u1, u2, rtol=1e-12, atol=1e-14)
