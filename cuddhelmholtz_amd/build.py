@@ -26,7 +26,9 @@ HIP_FLAGS = ["-x", "hip", f"--offload-arch={ARCH}", "-munsafe-fp-atomics", "-ffp
 
 # per-file extra flags: SLP-packing the fp32 time-stepping loop into v_pk_* is an anti-lever on gfx950
 # (a v_pk_fma_f32 is no faster than two v_fma_f32 and blocks DPP folding)
-EXTRA_FLAGS = {"ddh.hip": ["-fno-slp-vectorize"]}
+# -amdgpu-mfma-vgpr-form: keep the 4x4x1 MFMA accumulators in VGPRs (gfx950 has a unified file) instead of
+# shuttling them through AGPRs with v_accvgpr_read/write
+EXTRA_FLAGS = {"ddh.hip": ["-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 
 # host sources that contain device code (device lambdas) and must be compiled as HIP
 HIP_HOST_SOURCES = {"capi.cpp"}

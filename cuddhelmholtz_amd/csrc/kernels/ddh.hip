@@ -15,6 +15,7 @@
 //   * `ddh_block_kernel` (any n_basis <= 10) runs one subdomain per workgroup
 //     with the field staged in LDS, 3 barriers per stiffness sweep.
 #include <algorithm>
+#include <cmath>
 
 #include "common.hpp"
 
@@ -24,8 +25,10 @@ struct cuddh_ddh_plan
 {
     cuddh_ddh_desc d;
     int is_f64;
-    int kernel; // 1 block, 2 wave, 3 wave with hand-folded DPP FMAs (fp32)
+    int kernel; // 1 block, 2 wave, 3 wave with hand-folded DPP FMAs (fp32), 4 = 3 + MFMA for the in-lane contractions,
+                // 5 dense element matrix on the matrix cores (fp32, uniform geometry)
     int nodes;  // nb*nb*nel1d*nel1d
+    float *Aop = nullptr; // kernel 5: element stiffness matrix as MFMA A operands, [4 k-steps][64 lanes]
 };
 
 namespace
@@ -138,21 +141,40 @@ namespace
     }
 #undef CUDDH_QP
 
-    template <bool ASM, typename Real>
+    // VAR 0: plain HIP; 1: DPP reads folded into the FMAs (fp32); 2: as 1, and the in-lane (eta) contractions run on the
+    // matrix pipe as v_mfma_f32_4x4x1_16b_f32 (one 4x4 block per element, exact fp32 FMA chains), beside the VALU
+    template <int VAR, typename Real>
     __device__ inline void wave_stiffness(const Real (&w)[4], Real (&z)[4], const Real (&gx)[4], const Real (&gy)[4], const Real (&gz)[4],
                                           const Real (&Dk)[4], const Real (&DTk)[4], const Real *__restrict__ Dm, Real mR, Real mL,
                                           Real mU, Real mD, int lane)
     {
+        constexpr bool ASM = VAR >= 1;
         Real ux[4], uy[4];
-        // eta derivative: in-lane, uniform coefficients D(l, i)
-#pragma unroll
-        for (int l = 0; l < 4; ++l)
+        // eta derivative uy(k,l) = sum_i D(l,i) u(k,i): in-lane
+        if constexpr (VAR == 2)
         {
-            Real s = Dm[l] * w[0];
+            // block = element, output row = l (register), column = k (lane): A_b[l] = D(l,i) is lane k==l's Dk[i],
+            // B_b[k] = u(k,i) is my w[i]
+            typedef float f4 __attribute__((ext_vector_type(4)));
+            f4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-            for (int i = 1; i < 4; ++i)
-                s += Dm[l + 4 * i] * w[i];
-            uy[l] = s;
+            for (int i = 0; i < 4; ++i)
+                acc = __builtin_amdgcn_mfma_f32_4x4x1f32(Dk[i], w[i], acc, 0, 0, 0);
+#pragma unroll
+            for (int l = 0; l < 4; ++l)
+                uy[l] = acc[l];
+        }
+        else
+        {
+#pragma unroll
+            for (int l = 0; l < 4; ++l)
+            {
+                Real s = Dm[l] * w[0];
+#pragma unroll
+                for (int i = 1; i < 4; ++i)
+                    s += Dm[l + 4 * i] * w[i];
+                uy[l] = s;
+            }
         }
         // xi derivative: u(i, l) sits in lane i of my quad
         if constexpr (ASM)
@@ -172,14 +194,29 @@ namespace
             quad_contract_asm(f1, DTk, zz);
         else
             quad_contract(f1, DTk, zz);
-#pragma unroll
-        for (int l = 0; l < 4; ++l)
+        if constexpr (VAR == 2)
         {
-            Real s = zz[l];
+            // A_b[l] = D(i,l) is lane k==l's DTk[i], B_b[k] = f2(k,i) is my f2[i]; accumulate onto the xi part
+            typedef float f4 __attribute__((ext_vector_type(4)));
+            f4 acc = {zz[0], zz[1], zz[2], zz[3]};
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                s += Dm[i + 4 * l] * f2[i];
-            zz[l] = s;
+                acc = __builtin_amdgcn_mfma_f32_4x4x1f32(DTk[i], f2[i], acc, 0, 0, 0);
+#pragma unroll
+            for (int l = 0; l < 4; ++l)
+                zz[l] = acc[l];
+        }
+        else
+        {
+#pragma unroll
+            for (int l = 0; l < 4; ++l)
+            {
+                Real s = zz[l];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    s += Dm[i + 4 * l] * f2[i];
+                zz[l] = s;
+            }
         }
         // assembly across elements.  xi neighbours: my k==3 column meets the k==0 column of lane+1 (and vice versa)
         if constexpr (ASM)
@@ -210,7 +247,7 @@ namespace
         }
     }
 
-    template <typename Real, bool ASM>
+    template <typename Real, int VAR>
     __global__ void __launch_bounds__(256) ddh_wave_kernel(DdhArgs<Real> A, const Real *__restrict__ Dmat, const Real *__restrict__ filt,
                                                           const Real *__restrict__ cs, const Real *__restrict__ sn)
     {
@@ -299,7 +336,7 @@ namespace
                 const Real kw = filt[it];
                 Real z[4], ph[4], qh[4];
 
-                wave_stiffness<ASM>(p, z, gx, gy, gz, Dk, DTk, Dmat, mR, mL, mU, mD, lane);
+                wave_stiffness<VAR>(p, z, gx, gy, gz, Dk, DTk, Dmat, mR, mL, mU, mD, lane);
 #pragma unroll
                 for (int l = 0; l < 4; ++l)
                 {
@@ -308,7 +345,7 @@ namespace
                     qh[l] = q[l] + half_dt * dq;
                     p[l] -= dt * qh[l];
                 }
-                wave_stiffness<ASM>(ph, z, gx, gy, gz, Dk, DTk, Dmat, mR, mL, mU, mD, lane);
+                wave_stiffness<VAR>(ph, z, gx, gy, gz, Dk, DTk, Dmat, mR, mL, mU, mD, lane);
 #pragma unroll
                 for (int l = 0; l < 4; ++l)
                 {
@@ -358,6 +395,190 @@ namespace
                     A.update[A.n_lambda + wslot] = -mu + S * u[l];
                 }
             }
+        }
+    }
+
+    // ---------------------------------------------------------------- dense element matrix on the matrix cores (NB = 4, uniform geometry)
+    // When every element of every subdomain has the same metric tensor (always the case on the uniform_rect
+    // meshes DDH supports) the element-local part of a stiffness sweep is Z = K U with one 16x16 element matrix K
+    // and U = (16 nodes) x (16 elements of the subdomain): exactly one 16x16x16 product, i.e. four
+    // v_mfma_f32_16x16x4_f32 per sweep on the matrix pipe, leaving the VALU only the assembly and the RK2 update.
+    // Lane = element + 16 * h, register index = l (eta node): the B-operand map B[kk][j] with kk = 4 s + (lane >> 4),
+    // j = lane & 15 makes register s of a lane the node (h, l = s); the rows of K are ordered m = 4 h + l so that the
+    // C/D map (row = 4 (lane >> 4) + reg) returns the result in the same layout (h = k, the xi node).
+    // On gfx950 the f32 MFMA runs at the vector rate and does not overlap with VALU work, so what counts is the
+    // number of issue cycles: 4 MFMAs (128 cycles) replace the ~80 VALU instructions (160 cycles + DPP hazards) of the
+    // sum-factorised sweep, and the xi-neighbour exchange goes through ds_bpermute (LDS pipe, no VALU slots); a
+    // variant with odd elements stored mirrored in xi so that every exchange is a DPP row shift measured 24 % slower
+    // (96 instead of 72 VALU instructions per time step).
+    __global__ void __launch_bounds__(256) ddh_mfma_kernel(DdhArgs<float> A, const float *__restrict__ Aop, const float *__restrict__ filt,
+                                                          const float *__restrict__ cs, const float *__restrict__ sn)
+    {
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        const int lane = threadIdx.x & 63;
+        const int s = A.dom_begin + blockIdx.x * 4 + (threadIdx.x >> 6);
+        if (s >= A.dom_end)
+            return; // wave-uniform, no barriers in this kernel
+
+        const int k = lane >> 4, el = lane & 15, ex = el & 3, ey = el >> 2;
+        const int fdof = A.s_fdof[s];
+        const int *sI = A.sI + 256 * (size_t)s;
+        const size_t dbase = (size_t)A.mx_dof * s, fbase = (size_t)A.mx_fdof * s;
+
+        float invm[4], Hi[4], F[4], Gf[4], p[4], q[4], u[4], v[4];
+#pragma unroll
+        for (int l = 0; l < 4; ++l)
+        {
+            const int d = sI[k + 4 * (l + 4 * el)];
+            const float ai = A.a[dbase + d], mi = A.m[dbase + d];
+            invm[l] = 1.0f / (ai * ai * mi);
+            float f = 0, gg = 0, h = 0;
+            if (A.x)
+            {
+                const int gidx = A.gI[dbase + d];
+                f = static_cast<float>(A.x[gidx]);
+                gg = static_cast<float>(A.x[A.g_ndof + gidx]);
+            }
+            if (d < fdof)
+            {
+                h = A.H[fbase + d];
+                if (A.lambda)
+                {
+                    const int slot = A.B[d + (size_t)A.mx_fdof * (0 + 2 * (size_t)s)];
+                    if (slot >= 0)
+                    {
+                        f += h * A.lambda[slot];
+                        gg += h * A.lambda[A.n_lambda + slot];
+                    }
+                }
+                h *= ai;
+            }
+            F[l] = f;
+            Gf[l] = gg;
+            Hi[l] = h;
+            p[l] = q[l] = u[l] = v[l] = 0;
+        }
+        float Ka[4];
+#pragma unroll
+        for (int st = 0; st < 4; ++st)
+            Ka[st] = Aop[64 * st + lane];
+
+        // xi neighbours live in another 16-lane row (k = 3 of element ex meets k = 0 of element ex + 1): ds_bpermute;
+        // eta neighbours are 4 lanes away in the same row: DPP row_shl/shr:4
+        const bool hasR = (k == 3 && ex < 3), hasL = (k == 0 && ex > 0);
+        const int partner = hasR ? (el + 1) : (hasL ? (el - 1 + 48) : lane);
+        const float mX = (hasR || hasL) ? 1.0f : 0.0f;
+        const float mU = (ey < 3) ? 1.0f : 0.0f, mD = (ey > 0) ? 1.0f : 0.0f;
+
+        auto sweep = [&](const float (&w)[4], float (&z)[4])
+        {
+            f4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int st = 0; st < 4; ++st)
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(Ka[st], w[st], acc, 0, 0, 0);
+            float fx[4];
+#pragma unroll
+            for (int l = 0; l < 4; ++l)
+                fx[l] = __shfl(acc[l], partner, 64);
+#pragma unroll
+            for (int l = 0; l < 4; ++l)
+                z[l] = acc[l] + mX * fx[l];
+            const float from_above = dpp_read<0x104>(z[0]); // row_shl:4 : lane + 4 = element above
+            const float from_below = dpp_read<0x114>(z[3]); // row_shr:4
+            z[3] += mU * from_above;
+            z[0] += mD * from_below;
+        };
+
+        const float dt = A.dt, half_dt = 0.5f * A.dt;
+        const int nt = A.nt;
+        for (int whit = 0; whit < WH_ITERS; ++whit)
+        {
+            {
+                const float k0 = filt[0];
+#pragma unroll
+                for (int l = 0; l < 4; ++l)
+                {
+                    p[l] = u[l];
+                    q[l] = v[l];
+                    u[l] *= k0;
+                    v[l] *= k0;
+                }
+            }
+            for (int it = 1; it <= nt; ++it)
+            {
+                const float c0 = cs[2 * it - 2], s0 = sn[2 * it - 2];
+                const float c1 = cs[2 * it - 1], s1 = sn[2 * it - 1];
+                const float kw = filt[it];
+                float z[4], ph[4], qh[4];
+                sweep(p, z);
+#pragma unroll
+                for (int l = 0; l < 4; ++l)
+                {
+                    const float dq = ((z[l] - Hi[l] * q[l]) + c0 * F[l] + s0 * Gf[l]) * invm[l];
+                    ph[l] = p[l] - half_dt * q[l];
+                    qh[l] = q[l] + half_dt * dq;
+                    p[l] -= dt * qh[l];
+                }
+                sweep(ph, z);
+#pragma unroll
+                for (int l = 0; l < 4; ++l)
+                {
+                    const float dq = ((z[l] - Hi[l] * qh[l]) + c1 * F[l] + s1 * Gf[l]) * invm[l];
+                    q[l] += dt * dq;
+                    u[l] += kw * p[l];
+                    v[l] += kw * q[l];
+                }
+            }
+        }
+
+        const float rw = 1.0f / A.omega;
+#pragma unroll
+        for (int l = 0; l < 4; ++l)
+        {
+            v[l] *= rw;
+            const bool owner = !(k == 0 && ex > 0) && !(l == 0 && ey > 0);
+            if (!owner)
+                continue;
+            const int d = sI[k + 4 * (l + 4 * el)];
+            if (A.y)
+            {
+                const int gidx = A.gI[dbase + d];
+                const float M = A.m[dbase + d] * A.gmi[dbase + d];
+                atomic_add(A.y + gidx, static_cast<double>(M * u[l]));
+                atomic_add(A.y + A.g_ndof + gidx, static_cast<double>(M * v[l]));
+            }
+            if (A.update && d < fdof)
+            {
+                const int wslot = A.B[d + (size_t)A.mx_fdof * (1 + 2 * (size_t)s)];
+                if (wslot >= 0)
+                {
+                    float lam = 0, mu = 0;
+                    if (A.lambda)
+                    {
+                        const int rslot = A.B[d + (size_t)A.mx_fdof * (0 + 2 * (size_t)s)];
+                        if (rslot >= 0)
+                        {
+                            lam = A.lambda[rslot];
+                            mu = A.lambda[A.n_lambda + rslot];
+                        }
+                    }
+                    const float S = 2.0f * A.a[dbase + d] * A.omega;
+                    A.update[wslot] = -lam - S * v[l];
+                    A.update[A.n_lambda + wslot] = -mu + S * u[l];
+                }
+            }
+        }
+    }
+
+    // is the metric tensor of every element of every subdomain identical to that of (subdomain 0, element 0)?
+    __global__ void __launch_bounds__(256) ddh_uniform_check_kernel(long long n_nodes_total, const float *__restrict__ G, int *__restrict__ bad)
+    {
+        for (long long t = blockIdx.x * 256LL + threadIdx.x; t < n_nodes_total; t += gridDim.x * 256LL)
+        {
+            const int node = static_cast<int>(t % 16); // node within its element
+            const float *g = G + 3 * t, *g0 = G + 3 * node;
+            if (g[0] != g0[0] || g[1] != g0[1] || g[2] != g0[2])
+                atomicExch(bad, 1);
         }
     }
 
@@ -608,6 +829,79 @@ namespace
                            static_cast<const Real *>(d.wh_filter), static_cast<const Real *>(d.cs), static_cast<const Real *>(d.sn));
     }
 
+    // Builds plan->Aop for kernel 5.  Returns 0 on success, -1 if the geometry is not uniform, > 0 on a HIP error.
+    int build_dense_element_matrix(cuddh_ddh_plan *p)
+    {
+        const cuddh_ddh_desc &d = p->d;
+        const float *G = static_cast<const float *>(d.G);
+        int *flag = nullptr;
+        hipError_t e = hipMalloc(&flag, sizeof(int));
+        if (e != hipSuccess)
+            return static_cast<int>(e);
+        (void)hipMemset(flag, 0, sizeof(int));
+        const long long n_nodes = 256LL * d.n_domains;
+        hipLaunchKernelGGL(ddh_uniform_check_kernel, dim3(stream_grid(n_nodes, 256)), dim3(256), 0, nullptr, n_nodes, G, flag);
+        int bad = 1;
+        e = hipMemcpy(&bad, flag, sizeof(int), hipMemcpyDeviceToHost);
+        (void)hipFree(flag);
+        if (e != hipSuccess)
+            return static_cast<int>(e);
+        if (bad)
+            return -1;
+
+        float hD[16], hG[48];
+        e = hipMemcpy(hD, d.D, sizeof hD, hipMemcpyDeviceToHost);
+        if (e == hipSuccess)
+            e = hipMemcpy(hG, G, sizeof hG, hipMemcpyDeviceToHost);
+        if (e != hipSuccess)
+            return static_cast<int>(e);
+
+        // K[n_out][n_in], n = k + 4 l: one stiffness sweep (source/DDH.cpp:60-109) applied to unit vectors, in double
+        auto Dm = [&](int a, int b) { return static_cast<double>(hD[a + 4 * b]); }; // D(a,b)
+        double K[16][16];
+        for (int nin = 0; nin < 16; ++nin)
+        {
+            double U[16] = {0};
+            U[nin] = 1.0;
+            double f1[16], f2[16];
+            for (int l = 0; l < 4; ++l)
+                for (int k = 0; k < 4; ++k)
+                {
+                    double ux = 0, uy = 0;
+                    for (int i = 0; i < 4; ++i)
+                    {
+                        ux += Dm(k, i) * U[i + 4 * l];
+                        uy += Dm(l, i) * U[k + 4 * i];
+                    }
+                    const float *g = hG + 3 * (k + 4 * l);
+                    f1[k + 4 * l] = g[0] * ux + g[1] * uy;
+                    f2[k + 4 * l] = g[1] * ux + g[2] * uy;
+                }
+            for (int l = 0; l < 4; ++l)
+                for (int k = 0; k < 4; ++k)
+                {
+                    double su = 0;
+                    for (int i = 0; i < 4; ++i)
+                        su += Dm(i, k) * f1[i + 4 * l] + Dm(i, l) * f2[k + 4 * i];
+                    K[k + 4 * l][nin] = su;
+                }
+        }
+        // A operand of step st, lane ln:  A[i = ln & 15][kk = 4 st + (ln >> 4)] = K'[m = i][nu = kk],
+        // m = 4 k_out + l_out, nu = 4 l_in + k_in
+        float hA[256];
+        for (int st = 0; st < 4; ++st)
+            for (int ln = 0; ln < 64; ++ln)
+            {
+                const int m = ln & 15, nu = 4 * st + (ln >> 4);
+                const int k_out = m >> 2, l_out = m & 3, l_in = nu >> 2, k_in = nu & 3;
+                hA[64 * st + ln] = static_cast<float>(K[k_out + 4 * l_out][k_in + 4 * l_in]);
+            }
+        e = hipMalloc(reinterpret_cast<void **>(&p->Aop), sizeof hA);
+        if (e == hipSuccess)
+            e = hipMemcpy(p->Aop, hA, sizeof hA, hipMemcpyHostToDevice);
+        return static_cast<int>(e);
+    }
+
     template <typename Real>
     int apply(const cuddh_ddh_plan *plan, int dom_begin, int dom_end, const double *x, double *y, int zero_y, const Real *lambda,
               Real *update, void *stream)
@@ -654,18 +948,28 @@ namespace
         A.lambda = lambda;
         A.update = update;
 
-        if (plan->kernel == 2 || plan->kernel == 3)
+        if (plan->kernel == 5)
         {
-            // kernel 3 (hand-folded DPP FMAs) exists in fp32 only; fp64 always takes the generic form
-            constexpr bool can_asm = sizeof(Real) == 4;
-            if (can_asm && plan->kernel == 3)
-                hipLaunchKernelGGL((ddh_wave_kernel<Real, can_asm>), dim3((n_local + 3) / 4), dim3(256), 0, st, A,
-                                   static_cast<const Real *>(d.D), static_cast<const Real *>(d.wh_filter),
-                                   static_cast<const Real *>(d.cs), static_cast<const Real *>(d.sn));
+            if constexpr (sizeof(Real) == 4)
+            {
+                hipLaunchKernelGGL(ddh_mfma_kernel, dim3((n_local + 3) / 4), dim3(256), 0, st, A, plan->Aop, static_cast<const float *>(d.wh_filter),
+                                   static_cast<const float *>(d.cs), static_cast<const float *>(d.sn));
+                return launch_status();
+            }
+        }
+        if (plan->kernel >= 2)
+        {
+            // kernels 3 and 4 exist in fp32 only; fp64 always takes the plain form
+            constexpr int v3 = sizeof(Real) == 4 ? 1 : 0, v4 = sizeof(Real) == 4 ? 2 : 0;
+            const dim3 grid((n_local + 3) / 4), block(256);
+            const Real *D = static_cast<const Real *>(d.D), *fl = static_cast<const Real *>(d.wh_filter);
+            const Real *cs = static_cast<const Real *>(d.cs), *sn = static_cast<const Real *>(d.sn);
+            if (plan->kernel == 4)
+                hipLaunchKernelGGL((ddh_wave_kernel<Real, v4>), grid, block, 0, st, A, D, fl, cs, sn);
+            else if (plan->kernel == 3 || plan->kernel == 5)
+                hipLaunchKernelGGL((ddh_wave_kernel<Real, v3>), grid, block, 0, st, A, D, fl, cs, sn);
             else
-                hipLaunchKernelGGL((ddh_wave_kernel<Real, false>), dim3((n_local + 3) / 4), dim3(256), 0, st, A,
-                                   static_cast<const Real *>(d.D), static_cast<const Real *>(d.wh_filter),
-                                   static_cast<const Real *>(d.cs), static_cast<const Real *>(d.sn));
+                hipLaunchKernelGGL((ddh_wave_kernel<Real, 0>), grid, block, 0, st, A, D, fl, cs, sn);
             return launch_status();
         }
 
@@ -705,7 +1009,7 @@ extern "C"
     int cuddh_hip_ddh_plan_create(cuddh_ddh_plan **out, const cuddh_ddh_desc *desc, int is_f64, int kernel)
     {
         *out = nullptr;
-        if (!desc || desc->nb < 2 || desc->nb > 10 || desc->nel1d < 1)
+        if (!desc || desc->nb < 2 || desc->nb > 10 || desc->nel1d < 1 || kernel < 0 || kernel > 5)
             return static_cast<int>(hipErrorInvalidValue);
         const int nodes = desc->nb * desc->nb * desc->nel1d * desc->nel1d;
         if (nodes > 256)
@@ -718,7 +1022,7 @@ extern "C"
         p->kernel = 1;
 
         const bool wave_shape = (desc->nb == 4 && desc->nel1d == 4);
-        if ((kernel == 2 || kernel == 3) && !wave_shape)
+        if (kernel >= 2 && !wave_shape)
         {
             delete p;
             return static_cast<int>(hipErrorInvalidValue);
@@ -744,8 +1048,25 @@ extern "C"
                 return static_cast<int>(e);
             }
             if (!bad)
-                p->kernel = (kernel == 2) ? 2 : 3; // auto prefers the folded-DPP form (fp64 runs the generic form either way)
-            else if (kernel == 2 || kernel == 3)
+                p->kernel = (kernel >= 2) ? kernel : 3; // auto prefers the folded-DPP form (fp64 runs the plain form either way)
+            else if (kernel >= 2)
+            {
+                delete p;
+                return static_cast<int>(hipErrorInvalidValue);
+            }
+            // kernel 5 (dense element matrix on the matrix cores) needs fp32 and one metric tensor for all elements
+            if (!bad && !is_f64 && (kernel == 0 || kernel == 5))
+            {
+                int err5 = build_dense_element_matrix(p);
+                if (err5 == 0)
+                    p->kernel = 5;
+                else if (kernel == 5)
+                {
+                    delete p;
+                    return err5 > 0 ? err5 : static_cast<int>(hipErrorInvalidValue);
+                }
+            }
+            else if (kernel == 5)
             {
                 delete p;
                 return static_cast<int>(hipErrorInvalidValue);
@@ -757,6 +1078,8 @@ extern "C"
 
     int cuddh_hip_ddh_plan_destroy(cuddh_ddh_plan *plan)
     {
+        if (plan && plan->Aop)
+            (void)hipFree(plan->Aop);
         delete plan;
         return 0;
     }

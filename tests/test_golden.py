@@ -68,7 +68,7 @@ def test_gpu_operators_match_golden(cuda, tag, kind, nb, omega):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("tag,kernel", [("ddh_8_4", 1), ("ddh_8_4", 2), ("ddh_8_4", 3), ("ddh_8_8", 1)])
+@pytest.mark.parametrize("tag,kernel", [("ddh_8_4", 1), ("ddh_8_4", 2), ("ddh_8_4", 3), ("ddh_8_4", 4), ("ddh_8_8", 1)])
 def test_gpu_ddh_matches_golden(cuda, tag, kernel):
     import torch
 
