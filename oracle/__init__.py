@@ -230,6 +230,21 @@ def linear_functional(disc: Discretization, f, nq: int = 0, c: float = 1.0) -> n
     return F
 
 
+def face_linear_functional(fs: FaceSpaceO, f, c: float = 1.0) -> np.ndarray:
+    """include/FaceLinearFunctional.hpp:111-124 (collocated form): F[I(k,e)] += c w_k detJ f(x_k), x on the edge
+    from its first to its second node (include/Edge.hpp:143-149)."""
+    d = fs.d
+    F = np.zeros(fs.size)
+    for e, eid in enumerate(fs.faces):
+        edge = d.mesh.edges[eid]
+        x0, x1 = d.mesh.xy[edge.nodes[0]], d.mesh.xy[edge.nodes[1]]
+        for k in range(d.nb):
+            t = 0.5 * (d.gll_x[k] + 1.0)
+            xk = x0 + (x1 - x0) * t
+            F[fs.fI[k, e]] += c * d.gll_w[k] * (edge.length / 2) * float(f(np.float64(xk[0]), np.float64(xk[1])))
+    return F
+
+
 def helmholtz_apply(disc, S: Stiffness, M: Mass, H: FaceMass, fs: FaceSpaceO, omega: float, x: np.ndarray) -> np.ndarray:
     """examples/Helmholtz.hpp:28-56"""
     n = disc.ndof

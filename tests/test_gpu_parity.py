@@ -444,3 +444,92 @@ def test_sharded_ddh_single_rank_equals_ddh(cuda):
     F.postprocess(b1, f, u1)
     sh.postprocess(b1, f, u2)
     assert torch.allclose(u1, u2, rtol=1e-12, atol=1e-14)
+
+
+def test_unpreconditioned_gmres_on_helmholtz_operator(cuda):
+    """BASELINE config 2 in miniature: GMRES(20) on the fused complex Helmholtz operator, against the oracle's
+    GMRES on the oracle's operator (same iteration count, fp64)."""
+    import torch
+
+    import cuddhelmholtz_amd as cd
+
+    nx, nb, omega = 12, 3, 5.0
+    mesh = cd.Mesh2D.uniform_rect(nx, -1.0, 1.0, nx, -1.0, 1.0)
+    fem = cd.H1Space(mesh, cd.Basis(nb))
+    fs = cd.FaceSpace(fem, mesh.boundary_edges())
+    om = oracle.Mesh.uniform_rect(nx, -1.0, 1.0, nx, -1.0, 1.0)
+    d = oracle.Discretization(om, nb)
+    ofs = oracle.FaceSpaceO(d, om.boundary_edges)
+    n = d.ndof
+    a2 = d.nodal(oracle.alpha_disk) ** 2
+    ax = np.ones(ofs.size)
+    A = cd.HelmholtzOperator(omega, to_dev(torch, a2, cuda), to_dev(torch, ax, cuda), fem, fs)
+    S, M, H = oracle.Stiffness(d), oracle.Mass(d, a2), oracle.FaceMass(ofs, ax)
+    bh = np.concatenate([oracle.linear_functional(d, oracle.gaussians(omega)), np.zeros(n)])
+    b = to_dev(torch, bh, cuda)
+    x = torch.zeros(2 * n, dtype=torch.float64, device=cuda)
+    out = cd.gmres(2 * n, x, A, b, 20, 4, 1e-30)
+    x_ref, info = oracle.gmres(lambda v: oracle.helmholtz_apply(d, S, M, H, ofs, omega, v), bh, m=20, maxit=4, tol=1e-30)
+    assert out.num_matvec == info["num_matvec"]
+    assert rel(x.cpu().numpy(), x_ref) < 1e-8
+    assert out.res_norm[-1] < out.res_norm[0]
+
+
+def test_poisson_pipeline(cuda):
+    """BASELINE config 1 in miniature: the flow of examples/Poisson.cpp:111-160 (lifting of Dirichlet data through
+    FaceLinearFunctional + FaceMassMatrix solve, StiffnessMatrix + orth, GMRES) against the same flow on the oracle."""
+    import torch
+
+    import cuddhelmholtz_amd as cd
+
+    nx, nb = 12, 3
+    mesh = cd.Mesh2D.uniform_rect(nx, -1.0, 1.0, nx, -1.0, 1.0)
+    fem = cd.H1Space(mesh, cd.Basis(nb))
+    faces = mesh.boundary_edges()
+    fs = cd.FaceSpace(fem, faces)
+    n, nf = fem.size(), fs.size()
+    z = lambda m: torch.zeros(m, dtype=torch.float64, device=cuda)  # noqa: E731
+    u, b, G, q, y = z(n), z(n), z(n), z(nf), z(nf)
+    S = cd.StiffnessMatrix(fem)
+
+    class Poisson:
+        def __call__(self, xin, yout):
+            S.action(xin, yout)
+            fs.orth(yout)
+
+    cd.linear_functional(fem, cd.CONSTANT, b, param=1.0)
+    fs.orth(b)
+    cd.face_linear_functional(fs, cd.MASS_POLY, y)
+    m, pinv = cd.FaceMassMatrix(fs), cd.DiagInvFaceMassMatrix(fs)
+    cd.gmres(nf, q, m, y, 5, 10, 1e-12, Precond=pinv)
+    fs.prolong(q, G)
+    tmp = z(n)
+    Poisson()(G, tmp)
+    b -= tmp
+    out = cd.gmres(n, u, Poisson(), b, 20, 20, 1e-10)
+    u += G
+
+    om = oracle.Mesh.uniform_rect(nx, -1.0, 1.0, nx, -1.0, 1.0)
+    d = oracle.Discretization(om, nb)
+    ofs = oracle.FaceSpaceO(d, list(faces))
+    So = oracle.Stiffness(d)
+
+    def Ao(v):
+        w = So.apply(v)
+        w[ofs.proj] = 0.0
+        return w
+
+    bo = oracle.linear_functional(d, lambda xx, yy: np.ones_like(xx))
+    bo[ofs.proj] = 0.0
+    yo = oracle.face_linear_functional(ofs, oracle.mass_poly)
+    assert rel(y.cpu().numpy(), yo) < 1e-12
+    Mo, po = oracle.FaceMass(ofs), oracle.diag_inv_facemass(ofs)
+    qo, _ = oracle.gmres(lambda v: po * Mo.apply(v), po * yo, m=5, maxit=10, tol=1e-12)
+    assert rel(q.cpu().numpy(), qo) < 1e-9
+    Go = np.zeros(d.ndof)
+    Go[ofs.proj] += qo
+    bo -= Ao(Go)
+    uo, info = oracle.gmres(Ao, bo, m=20, maxit=20, tol=1e-10)
+    uo += Go
+    assert out.success and info["success"]
+    assert rel(u.cpu().numpy(), uo) < 1e-7
