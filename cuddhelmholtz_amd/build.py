@@ -93,5 +93,36 @@ def build_native(verbose: bool = False, jobs: int = 6) -> Path:
     return LIB_PATH
 
 
+EXAMPLES_DIR = ROOT / "build" / "examples"
+REFERENCE_EXAMPLES = Path("/root/reference/examples")
+
+
+def build_examples(verbose: bool = False) -> list[Path]:
+    """Compiles the native drivers against csrc/include/cuddh.hpp: this repository's ddh_solve.cpp and, when the
+    reference tree is present, the reference's own examples/{DDH,Poisson,Helmholtz}.cpp UNCHANGED (drop-in check).
+    Binaries go to build/examples/ (git-ignored, shipped to the GPU box)."""
+    EXAMPLES_DIR.mkdir(parents=True, exist_ok=True)
+    jobs = [(CSRC / "examples" / "ddh_solve.cpp", "ddh_solve")]
+    if REFERENCE_EXAMPLES.exists():
+        jobs += [(REFERENCE_EXAMPLES / f"{n}.cpp", f"{n}_reference_driver") for n in ("DDH", "Poisson", "Helmholtz")]
+    outs = []
+    for src, name in jobs:
+        out = EXAMPLES_DIR / name
+        if out.exists() and out.stat().st_mtime > max(src.stat().st_mtime, LIB_PATH.stat().st_mtime):
+            outs.append(out)
+            continue
+        cmd = [hipcc(), "-O2", "-std=c++17", "-x", "hip", f"--offload-arch={ARCH}", "-munsafe-fp-atomics",
+               *[f"-I{p}" for p in INCLUDES], f"-I{CSRC / 'examples'}", f"-I{REFERENCE_EXAMPLES}", str(src), "-o", str(out),
+               f"-L{LIB_DIR}", "-lcuddh_amd", "-Wl,-rpath,$ORIGIN/../../cuddhelmholtz_amd/lib"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"building {name} failed:\n{r.stderr}")
+        outs.append(out)
+    return outs
+
+
 if __name__ == "__main__":
     print(build_native(verbose="-v" in sys.argv))
+    print(*build_examples(verbose="-v" in sys.argv))

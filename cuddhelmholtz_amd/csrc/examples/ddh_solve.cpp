@@ -1,0 +1,62 @@
+// Native C++ driver for the DDH path, written against csrc/include/cuddh.hpp (the same API the reference's
+// examples/DDH.cpp uses), with a command line instead of compile-time constants:
+//   ddh_solve [nx=128] [n_basis=4] [omega_over_pi=25.6] [gmres_m=20] [maxit=100] [tol=1e-4] [out_dir=solution]
+// Writes <out_dir>/xy.0000 and <out_dir>/ddh.0000 (raw fp64, like the reference) and prints one summary line.
+#include <chrono>
+#include <cstdlib>
+#include <string>
+
+#include "cuddh.hpp"
+#include "examples.hpp"
+
+using namespace cuddh;
+
+int main(int argc, char **argv)
+{
+    const int nx = argc > 1 ? std::atoi(argv[1]) : 128;
+    const int nb = argc > 2 ? std::atoi(argv[2]) : 4;
+    const double omega = M_PI * (argc > 3 ? std::atof(argv[3]) : 25.6);
+    const int m = argc > 4 ? std::atoi(argv[4]) : 20;
+    const int maxit = argc > 5 ? std::atoi(argv[5]) : 100;
+    const float tol = argc > 6 ? static_cast<float>(std::atof(argv[6])) : 1e-4f;
+    const std::string out_dir = argc > 7 ? argv[7] : "solution";
+
+    Mesh2D mesh = Mesh2D::uniform_rect(nx, -1.0, 1.0, nx, -1.0, 1.0);
+    Basis basis(nb);
+    H1Space fem(mesh, basis);
+    const int ndof = fem.size(), N = 2 * ndof;
+
+    host_device_dvec U(N), b(N), a(ndof);
+    double *d_U = U.device_write(), *d_b = b.device_write(), *d_a = a.device_write();
+
+    LinearFunctional l(fem);
+    DiagInvMassMatrix mi(fem);
+    l.action([=] __device__(const double X[2]) -> double
+    {
+        const double s = omega * omega;
+        const double r0 = (X[0] + 0.5) * (X[0] + 0.5) + X[1] * X[1];
+        const double r1 = (X[0] - 0.5) * (X[0] - 0.5) + (X[1] + 0.5) * (X[1] + 0.5);
+        return s / M_PI * (exp(-s * r0) + exp(-s * r1));
+    }, d_b);
+    l.action([] __device__(const double X[2]) -> double { return (X[0] * X[0] + X[1] * X[1] < 0.0625) ? 0.2 : 1.0; }, d_a);
+    mi.action(d_a, d_a);
+
+    DDH F(omega, a.host_read(), fem, nx, nx);
+    const int n_lambda = F.size();
+    HostDeviceArray<float> L(n_lambda), Y(n_lambda);
+    float *d_L = L.device_write(), *d_Y = Y.device_write();
+
+    const auto t0 = std::chrono::steady_clock::now();
+    F.rhs(d_b, d_Y);
+    solver_out out = gmres(n_lambda, d_L, &F, d_Y, m, maxit, tol, 0);
+    F.postprocess(d_L, d_b, d_U);
+    const double *h_U = U.host_read();
+    const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+
+    to_file(out_dir + "/xy.0000", N, fem.physical_coordinates(MemorySpace::HOST));
+    to_file(out_dir + "/ddh.0000", N, h_U);
+    std::cout << "ddh_solve nx=" << nx << " nb=" << nb << " ndof=" << ndof << " n_lambda=" << n_lambda << " success=" << out.success
+              << " num_iter=" << out.num_iter << " num_matvec=" << out.num_matvec << " rel_res=" << out.res_norm.back() / out.res_norm.front()
+              << " seconds=" << secs << std::endl;
+    return 0;
+}
