@@ -246,6 +246,15 @@ def helmholtz_roofline(cd, torch, dev, fem, mesh, omega, ndof):
     t = e0.elapsed_time(e1) * 1e-3 / reps
     b_alg = A.bytes_per_apply(False)
     gbs = b_alg / t / 1e9
+    # HBM traffic per apply from the PMC counters (collected in separate rocprofv3 --pmc passes and committed under
+    # profiles/; bench.py cannot run the profiler on itself): only quoted when it was measured for this very configuration
+    traffic = None
+    nx_now = int(round(math.sqrt(mesh.n_elem())))
+    for pmc in sorted((ROOT / "profiles").glob("r*/helm_pmc_traffic.json"), reverse=True):
+        rec = json.loads(pmc.read_text())
+        if rec.get("nx") == nx_now and rec.get("nb") == fem.basis.n:
+            traffic = rec["traffic_bytes_per_apply"]
+            break
     return {
         "bound": "hbm",
         "kernel": "helm_patch_kernel + helm_border_kernel (fused complex Helmholtz apply)" if A.fused() else "unfused operator sequence",
@@ -253,7 +262,7 @@ def helmholtz_roofline(cd, torch, dev, fem, mesh, omega, ndof):
         "peak": HBM_PEAK_GBS,
         "unit": "GB/s",
         "frac": gbs / HBM_PEAK_GBS,
-        "traffic": None,
+        "traffic": traffic,
         "algorithmic_bytes": b_alg,
         "layout_bytes": A.bytes_per_apply(True),
         "seconds_per_apply": t,

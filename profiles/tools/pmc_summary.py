@@ -10,7 +10,7 @@ for root in sys.argv[1:]:
         for r in csv.DictReader(open(f)):
             acc[r["Kernel_Name"][:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
         for k, cs in acc.items():
-            if not any(s in k for s in ("helm_patch", "helm_border", "ddh_wave", "ddh_block")):
+            if not any(s in k for s in ("helm_patch", "helm_border", "ddh_wave_kernel", "ddh_block", "ddh_mfma")):
                 continue
             print(k)
             for c, v in cs.items():
