@@ -1,0 +1,104 @@
+"""Size-independent properties at BASELINE.json's full sizes (the oracle cannot reach them in seconds):
+1024 x 1024 elements, n_basis 4 (9.4 M dofs, 65,536 subdomains) and 256 x 256 (config 2)."""
+import math
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def big(cuda):
+    import torch
+
+    import cuddhelmholtz_amd as cd
+
+    nx, nb = 1024, 4
+    mesh = cd.Mesh2D.uniform_rect(nx, -1.0, 1.0, nx, -1.0, 1.0)
+    fem = cd.H1Space(mesh, cd.Basis(nb))
+    assert fem.size() == (3 * nx + 1) ** 2 == 9443329
+    return dict(cd=cd, torch=torch, nx=nx, nb=nb, mesh=mesh, fem=fem, n=fem.size())
+
+
+def test_operator_invariants_at_full_size(cuda, big):
+    cd, torch, fem, n = big["cd"], big["torch"], big["fem"], big["n"]
+    one = torch.ones(n, dtype=torch.float64, device=cuda)
+    y = torch.empty_like(one)
+    cd.StiffnessMatrix(fem).action(one, y)  # constants are in the kernel of the stiffness operator
+    assert float(y.abs().max()) < 1e-11
+    cd.MassMatrix(fem).action(one, y)  # 1^T M 1 = area of [-1,1]^2
+    assert abs(float(y.sum()) - 4.0) < 1e-10
+    g = torch.Generator(device="cpu").manual_seed(3)
+    coef = (0.5 + torch.rand(n, generator=g, dtype=torch.float64)).to(cuda)
+    Mw = cd.MassMatrix(fem, coef)
+    x1 = torch.rand(n, generator=g, dtype=torch.float64).to(cuda)
+    x2 = torch.rand(n, generator=g, dtype=torch.float64).to(cuda)
+    y1, y2 = torch.empty_like(x1), torch.empty_like(x1)
+    Mw.action(x1, y1)
+    Mw.action(x2, y2)
+    # symmetry: x2^T M x1 == x1^T M x2
+    a, b = float(torch.dot(x2, y1)), float(torch.dot(x1, y2))
+    assert abs(a - b) <= 1e-12 * abs(a)
+
+
+def test_fused_helmholtz_linearity_symmetry_determinism_at_full_size(cuda, big):
+    cd, torch, mesh, fem, n, nx = big["cd"], big["torch"], big["mesh"], big["fem"], big["n"], big["nx"]
+    fs = cd.FaceSpace(fem, mesh.boundary_edges())
+    assert fs.size() == 4 * 3 * nx
+    omega = 32 * math.pi
+    a2 = torch.ones(n, dtype=torch.float64, device=cuda)
+    ax = torch.ones(fs.size(), dtype=torch.float64, device=cuda)
+    A = cd.HelmholtzOperator(omega, a2, ax, fem, fs)
+    assert A.fused()
+    assert A.bytes_per_apply() == 1535639584  # 1,535 MB at 1024^2, n_basis 4
+    g = torch.Generator(device="cpu").manual_seed(12345)
+    x = (2 * torch.rand(2 * n, generator=g, dtype=torch.float64) - 1).to(cuda)
+    z = (2 * torch.rand(2 * n, generator=g, dtype=torch.float64) - 1).to(cuda)
+    Ax, Az, Axz, Ax2 = (torch.empty_like(x) for _ in range(4))
+    A.action(x, Ax)
+    A.action(z, Az)
+    A.action(0.5 * x - 2.0 * z, Axz)
+    A.action(x, Ax2)
+    assert torch.equal(Ax, Ax2)  # no atomics anywhere in the fused path
+    lin = 0.5 * Ax - 2.0 * Az
+    assert float(torch.linalg.norm(Axz - lin) / torch.linalg.norm(lin)) < 1e-13
+    # "scal(-1, Av) makes the system symmetric" (examples/Helmholtz.hpp:55)
+    s1, s2 = float(torch.dot(z, Ax)), float(torch.dot(x, Az))
+    assert abs(s1 - s2) <= 1e-11 * max(abs(s1), abs(s2))
+    U = torch.empty_like(x)
+    A.action_unfused(x, U)  # the per-class kernels with fp64 atomics
+    assert float(torch.linalg.norm(U - Ax) / torch.linalg.norm(Ax)) < 1e-13
+
+
+def test_ddh_properties_at_full_size(cuda, big):
+    cd, torch, fem, n, nx = big["cd"], big["torch"], big["fem"], big["n"], big["nx"]
+    from cuddhelmholtz_amd.dist import ShardedDDH
+
+    omega = 32 * math.pi
+    F = cd.DDH(omega, np.ones(n), fem, nx, nx)
+    info = F.info()
+    assert (info["n_domains"], info["nt"], info["kernel"]) == (65536, 5120, 5)
+    assert F.size() == 4 * 1697280  # 25,792 shared dofs at 128^2 scale as (edges); checked against the closed form below
+    n_edges_between_subdomains = 2 * 256 * 255  # 256 x 256 subdomains
+    assert F.size() // 4 == n_edges_between_subdomains * 13
+    g = torch.Generator(device="cpu").manual_seed(7)
+    lam = (2 * torch.rand(F.size(), generator=g) - 1).to(cuda)
+    y1, y2, y3 = (torch.zeros_like(lam) for _ in range(3))
+    F.action(lam, y1)
+    F.action(lam, y2)
+    assert torch.equal(y1, y2)  # bitwise reproducible (fixed summation order)
+    F.action(2.0 * lam, y3)     # I - T is linear; scaling by 2 is exact in fp32
+    assert torch.equal(y3, 2.0 * y1)
+    # sharded in three unequal ranges == whole
+    upd_whole = torch.zeros_like(lam)
+    F.local_traces(0, 65536, None, lam, upd_whole)
+    upd_parts = torch.zeros_like(lam)
+    for d0, d1 in ((0, 10000), (10000, 40001), (40001, 65536)):
+        F.local_traces(d0, d1, None, lam, upd_parts)
+    assert torch.equal(upd_whole, upd_parts)
+    sh = ShardedDDH(F, 65536)
+    y4 = torch.zeros_like(lam)
+    sh.action(lam, y4)
+    assert torch.equal(y4, y1)
+    assert bool(torch.isfinite(y1).all())
