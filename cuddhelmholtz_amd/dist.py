@@ -24,13 +24,14 @@ def partition(n_items: int, rank: int, world: int) -> tuple[int, int]:
 
 
 class ShardedDDH:
-    def __init__(self, engine, n_domains: int, rank: int = 0, world: int = 1, group=None):
+    def __init__(self, engine, n_domains: int, rank: int = 0, world: int = 1, group=None, always_reduce: bool = False):
         self.engine = engine
         self.rank, self.world, self.group = rank, world, group
+        self.always_reduce = always_reduce  # issue the collective even for world == 1 (exercises the RCCL path on one GPU)
         self.d0, self.d1 = partition(n_domains, rank, world)
 
     def _all_reduce(self, t):
-        if self.world > 1:
+        if self.world > 1 or self.always_reduce:
             import torch.distributed as dist
 
             dist.all_reduce(t, group=self.group)
