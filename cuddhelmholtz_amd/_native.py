@@ -90,6 +90,10 @@ _sig("cuddh_hip_scal_inv_dev_f32", ci, ci, vp, vp, vp)
 for _n in ("dot", "sqdist"):
     _sig(f"cuddh_hip_{_n}_f64", ci, ci, vp, vp, vp, vp, vp)
     _sig(f"cuddh_hip_{_n}_f32", ci, ci, vp, vp, vp, vp, vp)
+_sig("cuddh_hip_mgs_stage_f64", ci, ci, vp, vp, vp, vp, vp, vp, vp)
+_sig("cuddh_hip_mgs_stage_f32", ci, ci, vp, vp, vp, vp, vp, vp, vp)
+_sig("cuddh_hip_mgs_finish_f64", ci, ci, vp, vp, vp, vp)
+_sig("cuddh_hip_mgs_finish_f32", ci, ci, vp, vp, vp, vp)
 _sig("cuddh_hip_nrm2_f64", ci, ci, vp, vp, vp, vp)
 _sig("cuddh_hip_nrm2_f32", ci, ci, vp, vp, vp, vp)
 for _t in ("f64", "f32", "i32"):

@@ -57,9 +57,12 @@ class Basis:
         self._h = N.handle(lib.cuddh_basis_create(n), "Basis")
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib.cuddh_basis_destroy(self._h)
-            self._h = None
+        h, self._h = getattr(self, "_h", None), None
+        if h and lib is not None:  # `lib` may already be torn down at interpreter exit
+            try:
+                lib.cuddh_basis_destroy(h)
+            except Exception:  # noqa: BLE001
+                pass
 
     def size(self) -> int:
         return self.n
@@ -82,9 +85,12 @@ class Mesh2D:
         self._h = handle
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib.cuddh_mesh_destroy(self._h)
-            self._h = None
+        h, self._h = getattr(self, "_h", None), None
+        if h and lib is not None:  # `lib` may already be torn down at interpreter exit
+            try:
+                lib.cuddh_mesh_destroy(h)
+            except Exception:  # noqa: BLE001
+                pass
 
     @staticmethod
     def uniform_rect(nx, ax, bx, ny, ay, by) -> "Mesh2D":
@@ -127,9 +133,12 @@ class H1Space:
         self._h = N.handle(lib.cuddh_h1space_create(mesh._h, basis._h), "H1Space")
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib.cuddh_h1space_destroy(self._h)
-            self._h = None
+        h, self._h = getattr(self, "_h", None), None
+        if h and lib is not None:  # `lib` may already be torn down at interpreter exit
+            try:
+                lib.cuddh_h1space_destroy(h)
+            except Exception:  # noqa: BLE001
+                pass
 
     def size(self) -> int:
         return lib.cuddh_h1space_size(self._h)
@@ -153,9 +162,12 @@ class FaceSpace:
         self._h = N.handle(lib.cuddh_facespace_create(fem._h, len(self.faces), _h(self.faces)), "FaceSpace")
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib.cuddh_facespace_destroy(self._h)
-            self._h = None
+        h, self._h = getattr(self, "_h", None), None
+        if h and lib is not None:  # `lib` may already be torn down at interpreter exit
+            try:
+                lib.cuddh_facespace_destroy(h)
+            except Exception:  # noqa: BLE001
+                pass
 
     def size(self):
         return lib.cuddh_facespace_size(self._h)
@@ -207,9 +219,12 @@ class EnsembleSpace:
         self.dims = d
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib.cuddh_ensemble_destroy(self._h)
-            self._h = None
+        h, self._h = getattr(self, "_h", None), None
+        if h and lib is not None:  # `lib` may already be torn down at interpreter exit
+            try:
+                lib.cuddh_ensemble_destroy(h)
+            except Exception:  # noqa: BLE001
+                pass
 
     def array(self, name: str) -> np.ndarray:
         shape = self._SHAPES[name](self.dims, self.fem.basis.n)
@@ -227,9 +242,12 @@ class _Operator:
         self._keep = keepalive
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib.cuddh_operator_destroy(self._h)
-            self._h = None
+        h, self._h = getattr(self, "_h", None), None
+        if h and lib is not None:  # `lib` may already be torn down at interpreter exit
+            try:
+                lib.cuddh_operator_destroy(h)
+            except Exception:  # noqa: BLE001
+                pass
 
     def action(self, *args):
         if len(args) == 2:
@@ -326,9 +344,12 @@ class DDH:
         self.omega = float(omega)
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib.cuddh_ddh_destroy(self._h)
-            self._h = None
+        h, self._h = getattr(self, "_h", None), None
+        if h and lib is not None:  # `lib` may already be torn down at interpreter exit
+            try:
+                lib.cuddh_ddh_destroy(h)
+            except Exception:  # noqa: BLE001
+                pass
 
     def size(self) -> int:
         return lib.cuddh_ddh_size(self._h)

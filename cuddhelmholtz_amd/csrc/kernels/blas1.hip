@@ -218,6 +218,92 @@ namespace
         return launch_status();
     }
 
+    // ---------------- fused modified Gram-Schmidt stage (one launch per projection instead of dot + reduce + axpy)
+    // stage:  h = sum(pin)            (the coefficient <w, v_prev> whose partial sums the previous stage left behind)
+    //         w <- w - h * v_prev     (skipped when v_prev == nullptr: first stage)
+    //         pout[block] = partial sum of <w, v_next>   (v_next == nullptr: <w, w>, for the norm)
+    // Every workgroup sums the same <= MAX_PARTIALS partials in the same order, so all of them use the same h.
+    template <typename T>
+    __global__ void __launch_bounds__(BLOCK) mgs_stage_kernel(int n, T *__restrict__ w, const T *__restrict__ vprev, const T *__restrict__ vnext,
+                                                              const T *__restrict__ pin, int npin, T *__restrict__ pout, T *__restrict__ hout)
+    {
+        __shared__ T h_sh;
+        T h = T(0);
+        if (vprev)
+        {
+            T a = T(0);
+            for (int i = threadIdx.x; i < npin; i += BLOCK)
+                a += pin[i];
+            const T s = block_sum(a);
+            if (threadIdx.x == 0)
+            {
+                h_sh = s;
+                if (blockIdx.x == 0)
+                    *hout = s;
+            }
+            __syncthreads();
+            h = h_sh;
+        }
+        T acc = T(0);
+        for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK)
+        {
+            T wi = w[i];
+            if (vprev)
+            {
+                wi -= h * vprev[i];
+                w[i] = wi;
+            }
+            acc += wi * (vnext ? vnext[i] : wi);
+        }
+        __syncthreads(); // block_sum reuses its LDS scratch
+        const T s = block_sum(acc);
+        if (threadIdx.x == 0)
+            pout[blockIdx.x] = s;
+    }
+
+    // nrm = sqrt(sum(pin));  *hout = nrm;  w <- w / nrm
+    template <typename T>
+    __global__ void __launch_bounds__(BLOCK) mgs_finish_kernel(int n, T *__restrict__ w, const T *__restrict__ pin, int npin, T *__restrict__ hout)
+    {
+        __shared__ T nrm_sh;
+        T a = T(0);
+        for (int i = threadIdx.x; i < npin; i += BLOCK)
+            a += pin[i];
+        const T s = block_sum(a);
+        if (threadIdx.x == 0)
+        {
+            nrm_sh = sqrt(s);
+            if (blockIdx.x == 0)
+                *hout = nrm_sh;
+        }
+        __syncthreads();
+        const T nrm = nrm_sh;
+        for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK)
+            w[i] = w[i] / nrm;
+    }
+
+    inline int mgs_grid(int n)
+    {
+        int g = stream_grid(n, BLOCK, 4);
+        return g > MAX_PARTIALS ? MAX_PARTIALS : g;
+    }
+
+    template <typename T>
+    int launch_mgs_stage(int n, T *w, const T *vprev, const T *vnext, const T *pin, T *pout, T *hout, void *stream)
+    {
+        const int g = mgs_grid(n);
+        hipLaunchKernelGGL((mgs_stage_kernel<T>), dim3(g), dim3(BLOCK), 0, as_stream(stream), n, w, vprev, vnext, pin, g, pout, hout);
+        return launch_status();
+    }
+
+    template <typename T>
+    int launch_mgs_finish(int n, T *w, const T *pin, T *hout, void *stream)
+    {
+        const int g = mgs_grid(n);
+        hipLaunchKernelGGL((mgs_finish_kernel<T>), dim3(g), dim3(BLOCK), 0, as_stream(stream), n, w, pin, g, hout);
+        return launch_status();
+    }
+
     // ---------------- indexed maps
     __global__ void __launch_bounds__(BLOCK) gather_kernel(int n, const int *__restrict__ proj, const double *__restrict__ x, double *__restrict__ y)
     {
@@ -251,7 +337,18 @@ namespace
 
 extern "C"
 {
-    size_t cuddh_hip_reduce_ws_bytes(void) { return MAX_PARTIALS * sizeof(double); }
+    size_t cuddh_hip_reduce_ws_bytes(void) { return 2 * MAX_PARTIALS * sizeof(double); }
+
+    int cuddh_hip_mgs_stage_f64(int n, double *w, const double *vprev, const double *vnext, const double *pin, double *pout, double *hout, void *s)
+    {
+        return launch_mgs_stage<double>(n, w, vprev, vnext, pin, pout, hout, s);
+    }
+    int cuddh_hip_mgs_stage_f32(int n, float *w, const float *vprev, const float *vnext, const float *pin, float *pout, float *hout, void *s)
+    {
+        return launch_mgs_stage<float>(n, w, vprev, vnext, pin, pout, hout, s);
+    }
+    int cuddh_hip_mgs_finish_f64(int n, double *w, const double *pin, double *hout, void *s) { return launch_mgs_finish<double>(n, w, pin, hout, s); }
+    int cuddh_hip_mgs_finish_f32(int n, float *w, const float *pin, float *hout, void *s) { return launch_mgs_finish<float>(n, w, pin, hout, s); }
 
     int cuddh_hip_axpby_f64(int n, double a, const double *x, double b, double *y, void *s)
     {

@@ -23,6 +23,10 @@ namespace cuddh
         inline int k_axpby_dev(int n, float sa, const float *a, const float *x, float b, float *y) { return cuddh_hip_axpby_dev_f32(n, sa, a, x, b, y, stream()); }
         inline int k_scal_inv_dev(int n, const double *a, double *x) { return cuddh_hip_scal_inv_dev_f64(n, a, x, stream()); }
         inline int k_scal_inv_dev(int n, const float *a, float *x) { return cuddh_hip_scal_inv_dev_f32(n, a, x, stream()); }
+        inline int k_mgs_stage(int n, double *w, const double *vp, const double *vn, const double *pi, double *po, double *h) { return cuddh_hip_mgs_stage_f64(n, w, vp, vn, pi, po, h, stream()); }
+        inline int k_mgs_stage(int n, float *w, const float *vp, const float *vn, const float *pi, float *po, float *h) { return cuddh_hip_mgs_stage_f32(n, w, vp, vn, pi, po, h, stream()); }
+        inline int k_mgs_finish(int n, double *w, const double *pi, double *h) { return cuddh_hip_mgs_finish_f64(n, w, pi, h, stream()); }
+        inline int k_mgs_finish(int n, float *w, const float *pi, float *h) { return cuddh_hip_mgs_finish_f32(n, w, pi, h, stream()); }
 
         // apply the k previous rotations to column h, then build rotation k that zeroes h[k+1]
         template <typename scalar>
@@ -148,17 +152,22 @@ namespace cuddh
                     A->action(vk, vk1);
                     out.num_matvec++;
 
-                    // modified Gram-Schmidt against v0..vk, coefficients kept on the device
-                    for (int j = 0; j < k1; ++j)
+                    // modified Gram-Schmidt against v0..vk as a chain of fused stages: stage j applies the projection
+                    // on v_{j-1} and leaves the partial sums of <w, v_j> (the last one <w, w>) for the next stage, so one
+                    // launch per basis vector does what dot + reduce + axpy did; coefficients stay on the device.
+                    // On breakdown (norm == 0) v_{k+1} becomes non-finite but is never used.
                     {
-                        const scalar *vj = V + static_cast<std::size_t>(j) * n;
-                        detail::check_hip(k_dot(n, vk1, vj, dcol + j, ws), "gmres dot");
-                        detail::check_hip(k_axpby_dev(n, -one, dcol + j, vj, one, vk1), "gmres axpy");
+                        scalar *pa = static_cast<scalar *>(ws), *pb = pa + cuddh_hip_reduce_ws_bytes() / (2 * sizeof(double));
+                        detail::check_hip(k_mgs_stage(n, vk1, static_cast<const scalar *>(nullptr), V, pa, pa, dcol), "gmres mgs");
+                        for (int j = 0; j < k1; ++j)
+                        {
+                            const scalar *vj = V + static_cast<std::size_t>(j) * n;
+                            const scalar *vnext = (j + 1 < k1) ? vj + n : nullptr;
+                            detail::check_hip(k_mgs_stage(n, vk1, vj, vnext, pa, pb, dcol + j), "gmres mgs");
+                            std::swap(pa, pb);
+                        }
+                        detail::check_hip(k_mgs_finish(n, vk1, pa, dcol + k1), "gmres normalise");
                     }
-                    detail::check_hip(k_nrm2(n, vk1, dcol + k1, ws), "gmres norm");
-                    // normalise on the device before the host has seen the norm; on breakdown (norm == 0)
-                    // v_{k+1} becomes non-finite but is never used
-                    detail::check_hip(k_scal_inv_dev(n, dcol + k1, vk1), "gmres scal");
 
                     scalar *h = H.data() + static_cast<std::size_t>(m1) * k;
                     detail::check_hip(cuddh_hip_stream_sync(stream()), "gmres sync");

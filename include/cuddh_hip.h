@@ -65,6 +65,16 @@ int cuddh_hip_nrm2_f32(int n, const float *x, float *result, void *ws, void *str
 /* result <- sum (x[i]-y[i])^2  (square root taken by the caller; source/linalg.cpp:103-137) */
 int cuddh_hip_sqdist_f64(int n, const double *x, const double *y, double *result, void *ws, void *stream);
 int cuddh_hip_sqdist_f32(int n, const float *x, const float *y, float *result, void *ws, void *stream);
+/* One stage of the modified Gram-Schmidt loop of source/gmres.cpp:167-172 in a single launch:
+ *   h = sum of the partial sums `pin` left by the previous stage (= <w, vprev>), stored to *hout;
+ *   w <- w - h * vprev;   pout <- per-workgroup partial sums of <w, vnext>  (vnext == NULL: <w, w>).
+ * vprev == NULL starts a chain (no update, pin/hout ignored).  pin and pout are the two halves of a workspace of
+ * cuddh_hip_reduce_ws_bytes() bytes, used alternately.  `finish` turns the <w,w> partials into the norm
+ * (*hout = ||w||) and normalises w (source/gmres.cpp:174-179).  Fixed summation order. */
+int cuddh_hip_mgs_stage_f64(int n, double *w, const double *vprev, const double *vnext, const double *pin, double *pout, double *hout, void *stream);
+int cuddh_hip_mgs_stage_f32(int n, float *w, const float *vprev, const float *vnext, const float *pin, float *pout, float *hout, void *stream);
+int cuddh_hip_mgs_finish_f64(int n, double *w, const double *pin, double *hout, void *stream);
+int cuddh_hip_mgs_finish_f32(int n, float *w, const float *pin, float *hout, void *stream);
 int cuddh_hip_copy_f64(int n, const double *x, double *y, void *stream);
 int cuddh_hip_copy_f32(int n, const float *x, float *y, void *stream);
 int cuddh_hip_copy_i32(int n, const int *x, int *y, void *stream);
