@@ -6,13 +6,40 @@
 #ifndef CUDDH_AMD_OPERATORS_HPP
 #define CUDDH_AMD_OPERATORS_HPP
 
+#include <cstddef>
+
 #include "blas1.hpp"
 #include "memory.hpp"
 #include "operator.hpp"
 #include "spaces.hpp"
 
+struct cuddh_helmholtz_plan;
+
 namespace cuddh
 {
+    namespace detail
+    {
+        /// Patch plan of one element operator (include/cuddh_hip.h, cuddh_hip_operator_plan_*): built on the first
+        /// action(), null when no specialised kernel exists for (n_basis, n_quad) or CUDDH_OPERATOR_PLAN=0.
+        class OperatorPlan
+        {
+        public:
+            OperatorPlan() = default;
+            ~OperatorPlan();
+            OperatorPlan(const OperatorPlan &) = delete;
+            OperatorPlan &operator=(const OperatorPlan &) = delete;
+
+            /// kind 0: stiffness (metric = G), 1: mass (metric = a); returns the plan or nullptr
+            const cuddh_helmholtz_plan *get(int kind, const H1Space &fem, int n_quad, const double *h_P, const double *h_D,
+                                            const double *d_metric) const;
+            std::size_t bytes(bool actual) const;
+
+        private:
+            mutable cuddh_helmholtz_plan *plan = nullptr;
+            mutable bool tried = false;
+        };
+    } // namespace detail
+
     /// (grad u, grad phi)
     class StiffnessMatrix : public Operator
     {
@@ -29,6 +56,8 @@ namespace cuddh
         const host_device_dvec &P() const { return _P; }
         const host_device_dvec &D() const { return _D; }
         const host_device_dvec &G() const { return _G; }
+        /// bytes one action() moves through the patch plan (0 when the generic kernel is in use)
+        std::size_t bytes_per_apply(bool actual = false) const { return plan.bytes(actual); }
 
     private:
         void setup(const QuadratureRule &quad);
@@ -36,6 +65,7 @@ namespace cuddh
         const H1Space &fem;
         const int ndof, n_elem, n_basis, n_quad;
         host_device_dvec _P, _D, _G;
+        detail::OperatorPlan plan;
     };
 
     /// (a u, phi)
@@ -53,6 +83,7 @@ namespace cuddh
         int quad_size() const { return n_quad; }
         const host_device_dvec &P() const { return _P; }
         const host_device_dvec &weights() const { return _a; }
+        std::size_t bytes_per_apply(bool actual = false) const { return plan.bytes(actual); }
 
     private:
         void setup(const double *a);
@@ -60,6 +91,7 @@ namespace cuddh
         const H1Space &fem;
         const int ndof, n_elem, n_basis, n_quad;
         host_device_dvec _P, _a;
+        detail::OperatorPlan plan;
     };
 
     /// inverse of the Gauss-Lobatto lumped mass matrix

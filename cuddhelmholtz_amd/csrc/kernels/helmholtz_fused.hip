@@ -810,6 +810,313 @@ namespace
         return (nb == 3 && nqS == 4 && nqM == 6) || (nb == 4 && nqS == 5 && nqM == 8) || (nb == 5 && nqS == 6 && nqM == 9) ||
                (nb == 2 && nqS == 3 && nqM == 5);
     }
+
+    HelmArgs plan_args(const cuddh_helmholtz_plan *p, const double *x, double *y)
+    {
+        HelmArgs A;
+        A.ndof = p->ndof;
+        A.max_loc = p->max_loc;
+        A.ncol = p->ncol;
+        A.nfcol = p->nfcol;
+        A.nqF = p->nqF;
+        A.n_slots = p->n_slots;
+        A.n_patches = p->n_patches;
+        A.xcd_chunk = (p->n_patches + 7) / 8;
+        A.omega = 0.0;
+        A.dof_off = p->dof_off;
+        A.dof_list = p->dof_list;
+        A.slot_of = p->slot_of;
+        A.patch_nel = p->patch_nel;
+        A.face_off = p->face_off;
+        A.face_id = p->face_id;
+        A.lidx = p->lidx;
+        A.face_lidx = p->face_lidx;
+        A.colour = p->colour;
+        A.face_col = p->face_col;
+        A.Gp = p->Gp;
+        A.aMp = p->aMp;
+        A.aF = p->aF;
+        A.x = x;
+        A.y = y;
+        A.part = p->part;
+        return A;
+    }
+
+    // ---------------------------------------------------------------- one real operator through the same plan
+    // y = [y +] c * S x  (KIND 0)  or  y = [y +] c * M x  (KIND 1) on a real vector.  Same patches, layouts and colour
+    // phases as the complex kernel; the two half-waves now work on two DIFFERENT patches (2*pair and 2*pair + 1), so
+    // every metric load instruction still fetches 2 x 256 contiguous bytes and no lane idles.
+    template <int NB, int NQ, int KIND>
+    __global__ void __launch_bounds__(64, (NB >= 5 ? 2 : 4)) op_patch_kernel(HelmArgs A, int accumulate, const double *__restrict__ P,
+                                                                             const double *__restrict__ D)
+    {
+        constexpr int NN = NB * NB, NP = (NN + 1) / 2;
+        extern __shared__ double lds[];
+        const int pair = (blockIdx.x & 7) * A.xcd_chunk + (blockIdx.x >> 3);
+        if (2 * pair >= A.n_patches)
+            return; // whole workgroup
+        const int lane = threadIdx.x;
+        const int half = lane >> 5, le = lane & 31;
+        const int ML = A.max_loc;
+        double *xs = lds;          // [2 patches][ML]
+        double *ys = lds + 2 * ML; // [2 patches][ML]
+        const int n_here = min(2, A.n_patches - 2 * pair);
+
+        for (int h = 0; h < n_here; ++h)
+        {
+            const int off = A.dof_off[2 * pair + h];
+            const int nloc = A.dof_off[2 * pair + h + 1] - off;
+            const int *dofs = A.dof_list + off;
+            for (int base = 0; base < nloc; base += 256)
+            {
+                int gi[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    gi[j] = dofs[min(base + 64 * j + lane, nloc - 1)];
+                double xv[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    xv[j] = A.x[gi[j]];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                {
+                    const int i = base + 64 * j + lane;
+                    if (i < nloc)
+                    {
+                        xs[h * ML + i] = xv[j];
+                        ys[h * ML + i] = 0.0;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+
+        // ------------------------------------------------------------ element phase
+        const bool have = half < n_here;
+        const int patch = have ? 2 * pair + half : 2 * pair; // a missing second patch re-reads the first (results dropped)
+        const bool active = have && le < A.patch_nel[patch];
+        const uint32_t *li = A.lidx + ((size_t)patch * NP) * PE + le;
+        const double *xc = xs + half * ML;
+        uint32_t lpk[NP];
+#pragma unroll
+        for (int j = 0; j < NP; ++j)
+            lpk[j] = li[j * PE];
+        auto lix_of = [&](int n) -> int { return (n & 1) ? static_cast<int>(lpk[n >> 1] >> 16) : static_cast<int>(lpk[n >> 1] & 0xFFFFu); };
+        const double keep = active ? 1.0 : 0.0;
+        double u[NN], out[NN];
+#pragma unroll
+        for (int n = 0; n < NN; ++n)
+        {
+            u[n] = keep * xc[lix_of(n)];
+            out[n] = 0.0;
+        }
+
+        if constexpr (KIND == 0)
+        {
+            const double *Gp = A.Gp + (size_t)patch * 3 * NQ * NQ * PE + le;
+#pragma unroll 1
+            for (int q = 0; q < NQ; ++q)
+            {
+                double g[3 * NQ];
+#pragma unroll
+                for (int r = 0; r < NQ; ++r)
+                {
+                    g[3 * r + 0] = Gp[((q * 3 + 0) * NQ + r) * PE];
+                    g[3 * r + 1] = Gp[((q * 3 + 1) * NQ + r) * PE];
+                    g[3 * r + 2] = Gp[((q * 3 + 2) * NQ + r) * PE];
+                }
+                double pu[NB], du[NB], t0[NB], t1[NB];
+#pragma unroll
+                for (int l = 0; l < NB; ++l)
+                {
+                    double a = 0.0, b = 0.0;
+#pragma unroll
+                    for (int k = 0; k < NB; ++k)
+                    {
+                        a += P[q + NQ * k] * u[k + NB * l];
+                        b += D[q + NQ * k] * u[k + NB * l];
+                    }
+                    pu[l] = a;
+                    du[l] = b;
+                    t0[l] = 0.0;
+                    t1[l] = 0.0;
+                }
+#pragma unroll
+                for (int r = 0; r < NQ; ++r)
+                {
+                    double dx = 0.0, dy = 0.0;
+#pragma unroll
+                    for (int l = 0; l < NB; ++l)
+                    {
+                        dx += P[r + NQ * l] * du[l];
+                        dy += D[r + NQ * l] * pu[l];
+                    }
+                    const double f0 = g[3 * r + 0] * dx + g[3 * r + 1] * dy;
+                    const double f1 = g[3 * r + 1] * dx + g[3 * r + 2] * dy;
+#pragma unroll
+                    for (int l = 0; l < NB; ++l)
+                    {
+                        t0[l] += P[r + NQ * l] * f0;
+                        t1[l] += D[r + NQ * l] * f1;
+                    }
+                }
+#pragma unroll
+                for (int l = 0; l < NB; ++l)
+#pragma unroll
+                    for (int k = 0; k < NB; ++k)
+                        out[k + NB * l] += D[q + NQ * k] * t0[l] + P[q + NQ * k] * t1[l];
+            }
+        }
+        else
+        {
+            const double *ap = A.aMp + (size_t)patch * NQ * NQ * PE + le;
+#pragma unroll 1
+            for (int q = 0; q < NQ; ++q)
+            {
+                double am[NQ];
+#pragma unroll
+                for (int r = 0; r < NQ; ++r)
+                    am[r] = ap[(q * NQ + r) * PE];
+                double pu[NB], t[NB];
+#pragma unroll
+                for (int l = 0; l < NB; ++l)
+                {
+                    double a = 0.0;
+#pragma unroll
+                    for (int k = 0; k < NB; ++k)
+                        a += P[q + NQ * k] * u[k + NB * l];
+                    pu[l] = a;
+                    t[l] = 0.0;
+                }
+#pragma unroll
+                for (int r = 0; r < NQ; ++r)
+                {
+                    double val = 0.0;
+#pragma unroll
+                    for (int l = 0; l < NB; ++l)
+                        val += P[r + NQ * l] * pu[l];
+                    val *= am[r];
+#pragma unroll
+                    for (int l = 0; l < NB; ++l)
+                        t[l] += P[r + NQ * l] * val;
+                }
+#pragma unroll
+                for (int l = 0; l < NB; ++l)
+#pragma unroll
+                    for (int k = 0; k < NB; ++k)
+                        out[k + NB * l] += P[q + NQ * k] * t[l];
+            }
+        }
+
+        // accumulate in colour phases (both patches at once: they use different halves of ys)
+        {
+            double *yc = ys + half * ML;
+            const int mycol = active ? A.colour[patch * PE + le] : -1;
+            for (int c = 0; c < A.ncol; ++c)
+            {
+                if (mycol == c)
+                {
+#pragma unroll
+                    for (int n = 0; n < NN; ++n)
+                        yc[lix_of(n)] += out[n];
+                }
+                __syncthreads();
+            }
+        }
+
+        // ------------------------------------------------------------ write out
+        const double c = A.omega; // the scale factor travels in the omega field
+        for (int h = 0; h < n_here; ++h)
+        {
+            const int off = A.dof_off[2 * pair + h];
+            const int nloc = A.dof_off[2 * pair + h + 1] - off;
+            const int *dofs = A.dof_list + off;
+            const int *slot = A.slot_of + off;
+            for (int base = 0; base < nloc; base += 256)
+            {
+                int si[4], gi[4];
+                double y0[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                {
+                    const int i = min(base + 64 * j + lane, nloc - 1);
+                    si[j] = slot[i];
+                    gi[j] = dofs[i];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    y0[j] = (accumulate && si[j] < 0) ? A.y[gi[j]] : 0.0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                {
+                    const int i = base + 64 * j + lane;
+                    if (i >= nloc)
+                        continue;
+                    if (si[j] < 0)
+                        A.y[gi[j]] = y0[j] + c * ys[h * ML + i];
+                    else
+                        A.part[si[j]] = c * ys[h * ML + i];
+                }
+            }
+        }
+    }
+
+    __global__ void __launch_bounds__(256) op_border_kernel(int n_shared, int accumulate, const int *__restrict__ shared_dof,
+                                                           const int *__restrict__ shared_off, const int *__restrict__ shared_slots,
+                                                           const double *__restrict__ part, double *__restrict__ y)
+    {
+        for (int j = blockIdx.x * 256 + threadIdx.x; j < n_shared; j += gridDim.x * 256)
+        {
+            const int g = shared_dof[j];
+            double s = accumulate ? y[g] : 0.0;
+            for (int t = shared_off[j]; t < shared_off[j + 1]; ++t)
+                s += part[shared_slots[t]];
+            y[g] = s;
+        }
+    }
+
+    // kind 0: stiffness with nq = nb + 1; kind 1: mass with nq = nb + 1 (a == 1) or 1 + 3 nb / 2 + 1 (weighted)
+    bool op_supported(int kind, int nb, int nq)
+    {
+        if (nb < 2 || nb > 5)
+            return false;
+        if (kind == 0)
+            return nq == nb + 1;
+        return kind == 1 && (nq == nb + 1 || nq == 2 + 3 * nb / 2);
+    }
+
+    template <int NB, int NQ, int KIND>
+    void launch_op_one(const cuddh_helmholtz_plan *p, const HelmArgs &A, int accumulate, hipStream_t st)
+    {
+        const size_t lds = (size_t)4 * p->max_loc * sizeof(double);
+        hipLaunchKernelGGL((op_patch_kernel<NB, NQ, KIND>), dim3(8 * A.xcd_chunk), dim3(64), lds, st, A, accumulate,
+                           KIND == 0 ? p->PS : p->PM, p->DS);
+    }
+
+    bool launch_op(const cuddh_helmholtz_plan *p, const HelmArgs &A, int accumulate, hipStream_t st)
+    {
+        const int kind = p->nqS > 0 ? 0 : 1, nq = kind == 0 ? p->nqS : p->nqM;
+#define CUDDH_OP_CASE(NB_, NQ_, K_)                      \
+    if (p->nb == NB_ && nq == NQ_ && kind == K_)         \
+    {                                                    \
+        launch_op_one<NB_, NQ_, K_>(p, A, accumulate, st); \
+        return true;                                     \
+    }
+        CUDDH_OP_CASE(2, 3, 0)
+        CUDDH_OP_CASE(3, 4, 0)
+        CUDDH_OP_CASE(4, 5, 0)
+        CUDDH_OP_CASE(5, 6, 0)
+        CUDDH_OP_CASE(2, 3, 1)
+        CUDDH_OP_CASE(3, 4, 1)
+        CUDDH_OP_CASE(4, 5, 1)
+        CUDDH_OP_CASE(5, 6, 1)
+        CUDDH_OP_CASE(2, 5, 1)
+        CUDDH_OP_CASE(3, 6, 1)
+        CUDDH_OP_CASE(4, 8, 1)
+        CUDDH_OP_CASE(5, 9, 1)
+#undef CUDDH_OP_CASE
+        return false;
+    }
 } // namespace
 
 extern "C"
@@ -828,14 +1135,12 @@ extern "C"
         return 0;
     }
 
-    int cuddh_hip_helmholtz_plan_create(cuddh_helmholtz_plan **out, int ndof, int n_elem, int nb, const int *h_I, const double *h_xy,
-                                        int nqS, const double *h_PS, const double *h_DS, const double *G_S, int nqM,
-                                        const double *h_PM, const double *a_M, int n_faces, const int *h_fI, const int *h_face_elem,
-                                        int nqF, const double *h_PF, const double *a_F)
+    // nqS == 0 or nqM == 0: a plan for a single real operator (the other tables are left empty)
+    static int build_plan(cuddh_helmholtz_plan **out, int ndof, int n_elem, int nb, const int *h_I, const double *h_xy, int nqS,
+                          const double *h_PS, const double *h_DS, const double *G_S, int nqM, const double *h_PM, const double *a_M,
+                          int n_faces, const int *h_fI, const int *h_face_elem, int nqF, const double *h_PF, const double *a_F)
     {
         *out = nullptr;
-        if (!supported(nb, nqS, nqM) || n_elem <= 0)
-            return static_cast<int>(hipErrorNotSupported);
 
         cuddh_helmholtz_plan *p = new cuddh_helmholtz_plan;
         p->ndof = ndof;
@@ -1028,9 +1333,13 @@ extern "C"
         ok(upload(&p->shared_dof, shared_dof));
         ok(upload(&p->shared_off, shared_off));
         ok(upload(&p->shared_slots, shared_slots));
-        ok(upload_raw(&p->PS, h_PS, (size_t)nqS * nb));
-        ok(upload_raw(&p->DS, h_DS, (size_t)nqS * nb));
-        ok(upload_raw(&p->PM, h_PM, (size_t)nqM * nb));
+        if (nqS > 0)
+        {
+            ok(upload_raw(&p->PS, h_PS, (size_t)nqS * nb));
+            ok(upload_raw(&p->DS, h_DS, (size_t)nqS * nb));
+        }
+        if (nqM > 0)
+            ok(upload_raw(&p->PM, h_PM, (size_t)nqM * nb));
         if (n_faces > 0)
             ok(upload_raw(&p->PF, h_PF, (size_t)nqF * nb));
         if (n_slots > 0)
@@ -1039,12 +1348,16 @@ extern "C"
         int *d_perm = nullptr;
         ok(upload(&d_perm, padded_perm));
         const long long nG = (long long)n_patches * 3 * nqS * nqS * PE, nA = (long long)n_patches * nqM * nqM * PE;
-        ok(static_cast<int>(hipMalloc(reinterpret_cast<void **>(&p->Gp), nG * sizeof(double))));
-        ok(static_cast<int>(hipMalloc(reinterpret_cast<void **>(&p->aMp), nA * sizeof(double))));
+        if (nG > 0)
+            ok(static_cast<int>(hipMalloc(reinterpret_cast<void **>(&p->Gp), nG * sizeof(double))));
+        if (nA > 0)
+            ok(static_cast<int>(hipMalloc(reinterpret_cast<void **>(&p->aMp), nA * sizeof(double))));
         if (!err)
         {
-            hipLaunchKernelGGL(repack_kernel, dim3(stream_grid(nG, 256)), dim3(256), 0, nullptr, nG, 3, nqS, d_perm, G_S, p->Gp);
-            hipLaunchKernelGGL(repack_kernel, dim3(stream_grid(nA, 256)), dim3(256), 0, nullptr, nA, 1, nqM, d_perm, a_M, p->aMp);
+            if (nG > 0)
+                hipLaunchKernelGGL(repack_kernel, dim3(stream_grid(nG, 256)), dim3(256), 0, nullptr, nG, 3, nqS, d_perm, G_S, p->Gp);
+            if (nA > 0)
+                hipLaunchKernelGGL(repack_kernel, dim3(stream_grid(nA, 256)), dim3(256), 0, nullptr, nA, 1, nqM, d_perm, a_M, p->aMp);
             ok(launch_status());
             ok(static_cast<int>(hipDeviceSynchronize()));
         }
@@ -1056,8 +1369,9 @@ extern "C"
             return err;
         }
 
-        p->bytes_alg = (size_t)n_elem * ((size_t)3 * nqS * nqS * 8 + (size_t)nqM * nqM * 8 + (size_t)nn * 4) + (size_t)ndof * 32 +
-                       (size_t)n_faces * ((size_t)nqF * 8 + (size_t)nb * 4);
+        const bool single = nqS == 0 || nqM == 0; // one real vector in, one out
+        p->bytes_alg = (size_t)n_elem * ((size_t)3 * nqS * nqS * 8 + (size_t)nqM * nqM * 8 + (size_t)nn * 4) +
+                       (size_t)ndof * (single ? 16 : 32) + (size_t)n_faces * ((size_t)nqF * 8 + (size_t)nb * 4);
         size_t exclusive = 0;
         for (int s : slot_of)
             exclusive += s < 0;
@@ -1068,37 +1382,61 @@ extern "C"
         return 0;
     }
 
+    int cuddh_hip_helmholtz_plan_create(cuddh_helmholtz_plan **out, int ndof, int n_elem, int nb, const int *h_I, const double *h_xy,
+                                        int nqS, const double *h_PS, const double *h_DS, const double *G_S, int nqM,
+                                        const double *h_PM, const double *a_M, int n_faces, const int *h_fI, const int *h_face_elem,
+                                        int nqF, const double *h_PF, const double *a_F)
+    {
+        *out = nullptr;
+        if (!supported(nb, nqS, nqM) || n_elem <= 0)
+            return static_cast<int>(hipErrorNotSupported);
+        return build_plan(out, ndof, n_elem, nb, h_I, h_xy, nqS, h_PS, h_DS, G_S, nqM, h_PM, a_M, n_faces, h_fI, h_face_elem, nqF,
+                          h_PF, a_F);
+    }
+
+    int cuddh_hip_operator_plan_create(cuddh_helmholtz_plan **out, int kind, int ndof, int n_elem, int nb, const int *h_I,
+                                       const double *h_xy, int nq, const double *h_P, const double *h_D, const double *metric)
+    {
+        *out = nullptr;
+        if (n_elem <= 0 || !op_supported(kind, nb, nq))
+            return static_cast<int>(hipErrorNotSupported);
+        if (kind == 0)
+            return build_plan(out, ndof, n_elem, nb, h_I, h_xy, nq, h_P, h_D, metric, 0, nullptr, nullptr, 0, nullptr, nullptr, 0,
+                              nullptr, nullptr);
+        return build_plan(out, ndof, n_elem, nb, h_I, h_xy, 0, nullptr, nullptr, nullptr, nq, h_P, metric, 0, nullptr, nullptr, 0,
+                          nullptr, nullptr);
+    }
+
+    int cuddh_hip_operator_plan_apply(const cuddh_helmholtz_plan *p, double c, int accumulate, const double *x, double *y, void *stream)
+    {
+        if (!p || (p->nqS > 0) == (p->nqM > 0))
+            return static_cast<int>(hipErrorInvalidValue);
+        hipStream_t st = as_stream(stream);
+        HelmArgs A = plan_args(p, x, y);
+        A.omega = c;
+        const int n_pairs = (p->n_patches + 1) / 2;
+        A.xcd_chunk = (n_pairs + 7) / 8;
+        if (!launch_op(p, A, accumulate, st))
+            return static_cast<int>(hipErrorNotSupported);
+        int err = launch_status();
+        if (err)
+            return err;
+        if (p->n_shared > 0)
+        {
+            hipLaunchKernelGGL(op_border_kernel, dim3(stream_grid(p->n_shared, 256)), dim3(256), 0, st, p->n_shared, accumulate,
+                               p->shared_dof, p->shared_off, p->shared_slots, p->part, y);
+            err = launch_status();
+        }
+        return err;
+    }
+
     int cuddh_hip_helmholtz_apply(const cuddh_helmholtz_plan *p, double omega, const double *x, double *y, void *stream)
     {
         if (!p)
             return static_cast<int>(hipErrorInvalidValue);
         hipStream_t st = as_stream(stream);
-        HelmArgs A;
-        A.ndof = p->ndof;
-        A.max_loc = p->max_loc;
-        A.ncol = p->ncol;
-        A.nfcol = p->nfcol;
-        A.nqF = p->nqF;
-        A.n_slots = p->n_slots;
-        A.n_patches = p->n_patches;
-        A.xcd_chunk = (p->n_patches + 7) / 8;
+        HelmArgs A = plan_args(p, x, y);
         A.omega = omega;
-        A.dof_off = p->dof_off;
-        A.dof_list = p->dof_list;
-        A.slot_of = p->slot_of;
-        A.patch_nel = p->patch_nel;
-        A.face_off = p->face_off;
-        A.face_id = p->face_id;
-        A.lidx = p->lidx;
-        A.face_lidx = p->face_lidx;
-        A.colour = p->colour;
-        A.face_col = p->face_col;
-        A.Gp = p->Gp;
-        A.aMp = p->aMp;
-        A.aF = p->aF;
-        A.x = x;
-        A.y = y;
-        A.part = p->part;
 
         if (p->nb == 4)
             launch_patch<4, 5, 8>(p, A, st);

@@ -1,10 +1,49 @@
 // Operator classes: table set-up on the host, kernels through the C ABI.
 #include "cuddh/operators.hpp"
 
+#include <cstdlib>
+#include <vector>
+
 #include "cuddh_hip.h"
 
 namespace cuddh
 {
+    namespace detail
+    {
+        OperatorPlan::~OperatorPlan()
+        {
+            if (plan)
+                cuddh_hip_helmholtz_plan_destroy(plan);
+        }
+
+        const cuddh_helmholtz_plan *OperatorPlan::get(int kind, const H1Space &fem, int n_quad, const double *h_P, const double *h_D,
+                                                      const double *d_metric) const
+        {
+            if (tried)
+                return plan;
+            tried = true;
+            if (const char *e = std::getenv("CUDDH_OPERATOR_PLAN"))
+                if (std::atoi(e) == 0)
+                    return nullptr;
+            const int n_elem = fem.mesh().n_elem();
+            // element centroids: only used to group elements into compact patches
+            std::vector<double> centroid(static_cast<std::size_t>(2) * n_elem);
+            const double mid[2] = {0.0, 0.0};
+            for (int el = 0; el < n_elem; ++el)
+                fem.mesh().element(el)->physical_coordinates(mid, centroid.data() + 2 * el);
+            const int err = cuddh_hip_operator_plan_create(&plan, kind, fem.size(), n_elem, fem.basis().size(),
+                                                           fem.global_indices(MemorySpace::HOST), centroid.data(), n_quad, h_P, h_D,
+                                                           d_metric);
+            if (err == 801) // hipErrorNotSupported: the generic kernels cover every (n_basis, n_quad)
+                plan = nullptr;
+            else
+                check_hip(err, "operator plan");
+            return plan;
+        }
+
+        std::size_t OperatorPlan::bytes(bool actual) const { return cuddh_hip_helmholtz_plan_bytes(plan, actual ? 1 : 0); }
+    } // namespace detail
+
     namespace
     {
         host_device_dvec rule_weights(const QuadratureRule &quad)
@@ -47,6 +86,11 @@ namespace cuddh
 
     void StiffnessMatrix::action(double c, const double *x, double *y) const
     {
+        if (const cuddh_helmholtz_plan *pl = plan.get(0, fem, n_quad, _P.host_read(), _D.host_read(), _G.device_read()))
+        {
+            detail::check_hip(cuddh_hip_operator_plan_apply(pl, c, 1, x, y, stream()), "StiffnessMatrix::action");
+            return;
+        }
         detail::check_hip(cuddh_hip_stiffness_apply(n_elem, n_quad, n_basis, _P.device_read(), _D.device_read(),
                                                     _G.device_read(), fem.global_indices(MemorySpace::DEVICE), c, x, y,
                                                     stream()),
@@ -55,6 +99,11 @@ namespace cuddh
 
     void StiffnessMatrix::action(const double *x, double *y) const
     {
+        if (const cuddh_helmholtz_plan *pl = plan.get(0, fem, n_quad, _P.host_read(), _D.host_read(), _G.device_read()))
+        {
+            detail::check_hip(cuddh_hip_operator_plan_apply(pl, 1.0, 0, x, y, stream()), "StiffnessMatrix::action");
+            return;
+        }
         zeros(ndof, y);
         action(1.0, x, y);
     }
@@ -91,6 +140,11 @@ namespace cuddh
 
     void MassMatrix::action(double c, const double *x, double *y) const
     {
+        if (const cuddh_helmholtz_plan *pl = plan.get(1, fem, n_quad, _P.host_read(), nullptr, _a.device_read()))
+        {
+            detail::check_hip(cuddh_hip_operator_plan_apply(pl, c, 1, x, y, stream()), "MassMatrix::action");
+            return;
+        }
         detail::check_hip(cuddh_hip_mass_apply(n_elem, n_quad, n_basis, fem.global_indices(MemorySpace::DEVICE),
                                                _P.device_read(), _a.device_read(), c, x, y, stream()),
                           "MassMatrix::action");
@@ -98,6 +152,11 @@ namespace cuddh
 
     void MassMatrix::action(const double *x, double *y) const
     {
+        if (const cuddh_helmholtz_plan *pl = plan.get(1, fem, n_quad, _P.host_read(), nullptr, _a.device_read()))
+        {
+            detail::check_hip(cuddh_hip_operator_plan_apply(pl, 1.0, 0, x, y, stream()), "MassMatrix::action");
+            return;
+        }
         zeros(ndof, y);
         action(1.0, x, y);
     }

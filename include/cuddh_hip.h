@@ -151,6 +151,18 @@ int cuddh_hip_helmholtz_apply(const cuddh_helmholtz_plan *plan, double omega, co
 /* bytes the plan's apply reads+writes per call, by the SURVEY 8d formula and as actually laid out */
 size_t cuddh_hip_helmholtz_plan_bytes(const cuddh_helmholtz_plan *plan, int actual);
 
+/* The same plan machinery for ONE real operator -- the bandwidth path of StiffnessMatrix::action
+ * (source/StiffnessMatrix.cpp:186-205, kind 0, metric = G (3,nq,nq,n_elem)) and MassMatrix::action
+ * (source/MassMatrix.cpp:213-239, kind 1, metric = a (nq,nq,n_elem)):  y = [y +] c * Op x  without atomics
+ * and without a zero-fill (accumulate != 0 keeps the reference's action(c,x,y) meaning, 0 is action(x,y)).
+ * h_D is ignored for kind 1.  Returns hipErrorNotSupported (801) unless 2 <= nb <= 5 and nq is the rule the
+ * reference's constructors pick (nb+1; or 1+3nb/2+1 for the weighted mass); callers then use
+ * cuddh_hip_stiffness_apply / cuddh_hip_mass_apply.  destroy/bytes: the helmholtz_plan functions. */
+int cuddh_hip_operator_plan_create(cuddh_helmholtz_plan **plan, int kind, int ndof, int n_elem, int nb, const int *h_I,
+                                   const double *h_xy, int nq, const double *h_P, const double *h_D, const double *metric);
+int cuddh_hip_operator_plan_apply(const cuddh_helmholtz_plan *plan, double c, int accumulate, const double *x, double *y,
+                                  void *stream);
+
 /* ------------------------------------------------------------------ DDH local solves
  * source/DDH.cpp:15-58 (init_geom_factors): G (3, nb*nb*mx_elems, n_domains) as
  * Real triples (the reference stores float3), from J (2,2,nb,nb,g_elem). */

@@ -131,6 +131,43 @@ def test_stiffness_mass_apply(cuda, kind, nb):
     assert rel(z.cpu().numpy(), oracle.diag_inv_mass(d) * xh) < 1e-13
 
 
+@pytest.mark.parametrize("nb", [3, 4])
+def test_operator_plan_and_generic_kernels_agree(cuda, nb, monkeypatch):
+    """StiffnessMatrix / MassMatrix pick the patch-plan kernels (cuddh_hip_operator_plan_*) when one exists for
+    (n_basis, n_quad) and the generic batched kernels otherwise; CUDDH_OPERATOR_PLAN=0 forces the latter.  Both must
+    match the oracle; the plan path is also bitwise reproducible (no atomics)."""
+    import torch
+
+    import cuddhelmholtz_amd as cd
+
+    pm, om = meshes("unstructured")
+    fem = cd.H1Space(pm, cd.Basis(nb))
+    d = oracle.Discretization(om, nb)
+    rng = np.random.default_rng(100 + nb)
+    xh = rng.standard_normal(d.ndof)
+    coef = 0.5 + rng.random(d.ndof)
+    x = to_dev(torch, xh, cuda)
+    refS = oracle.Stiffness(d).apply(xh)
+    refM = oracle.Mass(d, coef).apply(xh)
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("CUDDH_OPERATOR_PLAN", mode)
+        S = cd.StiffnessMatrix(fem)
+        M = cd.MassMatrix(fem, to_dev(torch, coef, cuda))
+        y = torch.full((d.ndof,), -3.0, dtype=torch.float64, device=cuda)
+        S.action(x, y)
+        assert rel(y.cpu().numpy(), refS) < 1e-12
+        M.action(0.25, x, y)
+        assert rel(y.cpu().numpy(), refS + 0.25 * refM) < 1e-12
+        out[mode] = y.cpu().numpy().copy()
+        if mode == "1":
+            y2 = torch.full((d.ndof,), 11.0, dtype=torch.float64, device=cuda)
+            S.action(x, y2)
+            M.action(0.25, x, y2)
+            assert np.array_equal(y2.cpu().numpy(), out["1"])
+    assert rel(out["1"], out["0"]) < 1e-13
+
+
 @pytest.mark.parametrize("kind", ["structured", "unstructured"])
 @pytest.mark.parametrize("nb", [3, 4, 6])
 def test_facemass_and_facespace(cuda, kind, nb):
