@@ -58,6 +58,11 @@ def main() -> None:
     ap.add_argument("--nx", type=int, default=1024, help="elements per side (default: the metric's 1024)")
     ap.add_argument("--nb", type=int, default=4)
     ap.add_argument("--kernel", type=int, default=0, help="DDH kernel: 0 auto, 1 workgroup, 2 wavefront, 3 wavefront with DPP-folded FMAs")
+    ap.add_argument("--exchange", choices=("neighbour", "allreduce"), default="neighbour",
+                    help="N > 1: partitioned trace vectors with neighbour send/recv (default) or replicated vectors with one all-reduce")
+    ap.add_argument("--rehearse-gloo", action="store_true",
+                    help="rehearsal of the N > 1 host logic on ONE GPU: all ranks share cuda:0, process group on gloo with host-staged "
+                         "payloads (RCCL needs one GPU per rank).  Not a measurement.")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -75,13 +80,29 @@ def main() -> None:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    staged = args.rehearse_gloo
+    if staged:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     launched = "RANK" in os.environ and "MASTER_PORT" in os.environ  # under torch.distributed.run, even with one rank
     if world > 1 or launched:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if staged:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     cd.use_torch_stream()
+
+    def allred(t, op=None):
+        """all-reduce of a device tensor (through host memory in the gloo rehearsal)"""
+        op = dist.ReduceOp.SUM if op is None else op
+        if staged:
+            h = t.cpu()
+            dist.all_reduce(h, op=op)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, op=op)
 
     nx, nb = args.nx, args.nb
     omega = math.pi * nx / 32.0  # 32 pi at 1024, 16 pi at 512 (BASELINE.json configs 3 and 4)
@@ -104,12 +125,35 @@ def main() -> None:
     info = F.info()
     n = F.size()
     nd = info["n_domains"]
-    from cuddhelmholtz_amd.dist import ShardedDDH
+    from cuddhelmholtz_amd.dist import NeighbourShardedDDH, ShardedDDH
 
-    sh = ShardedDDH(F, nd, rank, world, always_reduce=dist.is_initialized())  # contiguous subdomain range + trace all-reduce
-
+    # N > 1: each rank solves a contiguous range of subdomains.  Default: trace vectors partitioned by slot ownership,
+    # traces for other ranks sent to the (<= 2) neighbouring ranks (grouped RCCL send/recv), inner products all-reduced.
+    # Fallback (--exchange allreduce, or if the start-up cross-check below fails): replicated vectors, one all-reduce.
+    sh_all = ShardedDDH(F, nd, rank, world, always_reduce=dist.is_initialized(), host_staging=staged)
     b = torch.zeros(n, dtype=torch.float32, device=dev)
-    sh.rhs(f, b)
+    sh_all.rhs(f, b)
+    exchange, exchange_note = ("allreduce" if world > 1 else "none"), ""
+    sh = sh_all
+    if world > 1 and args.exchange == "neighbour":
+        ok, sh_nb, b_nb = 0.0, None, None
+        try:
+            sh_nb = NeighbourShardedDDH(F, nd, rank, world, device=dev, host_staging=staged)
+            b_nb = torch.zeros_like(b)
+            sh_nb.rhs(f, b_nb)
+            # traces are copied, not summed: the assembled vector must be bitwise the all-reduce result
+            ok = 1.0 if torch.equal(sh_nb.full(b_nb), b) else 0.0
+            if ok == 0.0:
+                exchange_note = "neighbour exchange disagreed with the all-reduce assembly at start-up; fell back"
+        except Exception as e:  # noqa: BLE001 - keep the run alive on the proven path and say so
+            exchange_note = f"neighbour exchange unavailable ({type(e).__name__}: {e}); fell back"
+        flag = torch.tensor([ok], device=dev)
+        allred(flag, dist.ReduceOp.MIN)  # every rank takes the same branch
+        if float(flag.item()) == 1.0:
+            sh, b, exchange = sh_nb, b_nb, "neighbour"
+        elif not exchange_note:
+            exchange_note = "neighbour exchange failed its start-up check on another rank; fell back"
+    partitioned = exchange == "neighbour"
     torch.cuda.synchronize()
     t_setup = time.time() - t_setup
 
@@ -124,18 +168,28 @@ def main() -> None:
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
 
-    V[0].copy_(b / torch.linalg.norm(b))
+    bb = torch.dot(b, b).reshape(1)
+    if partitioned:
+        allred(bb)
+    V[0].copy_(b / torch.sqrt(bb))
 
     def arnoldi_step(k: int) -> None:
         vk, vk1 = V[k], V[k + 1]
-        # w = (I - T) v_k : local solves of this rank's subdomains, then reassemble the trace vector
+        # w = (I - T) v_k : local solves of this rank's subdomains, then the trace exchange / reassembly
         sh.traces(None, vk, upd)
         N.check(lib.cuddh_hip_copy_f32(n, p(vk), p(vk1), st))
         N.check(lib.cuddh_hip_axpby_f32(n, -1.0, p(upd), 1.0, p(vk1), st))
         for j in range(k + 1):
             N.check(lib.cuddh_hip_dot_f32(n, p(vk1), p(V[j]), p(hcol[j:]), p(ws), st))
+            if partitioned:  # the vectors are partitioned over the ranks: the coefficient is the sum of the local dots
+                allred(hcol[j:j + 1])
             N.check(lib.cuddh_hip_axpby_dev_f32(n, -1.0, p(hcol[j:]), p(V[j]), 1.0, p(vk1), st))
-        N.check(lib.cuddh_hip_nrm2_f32(n, p(vk1), p(hcol[k + 1:]), p(ws), st))
+        if partitioned:
+            N.check(lib.cuddh_hip_dot_f32(n, p(vk1), p(vk1), p(hcol[k + 1:]), p(ws), st))
+            allred(hcol[k + 1:k + 2])
+            hcol[k + 1:k + 2].sqrt_()
+        else:
+            N.check(lib.cuddh_hip_nrm2_f32(n, p(vk1), p(hcol[k + 1:]), p(ws), st))
         N.check(lib.cuddh_hip_scal_inv_dev_f32(n, p(hcol[k + 1:]), p(vk1), st))
         if k + 1 == gmres_m:  # restart: continue from the last basis vector
             V[0].copy_(vk1)
@@ -162,7 +216,7 @@ def main() -> None:
     elapsed = time.perf_counter() - t0
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        allred(tmax, dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     finite = bool(torch.isfinite(V).all().item())
 
@@ -196,7 +250,12 @@ def main() -> None:
             "g_ndof": ndof,
             "n_traces": n,
             "ddh_kernel": {1: "workgroup-per-subdomain", 2: "wavefront-per-subdomain", 3: "wavefront-per-subdomain, DPP-folded FMAs", 4: "wavefront-per-subdomain, DPP-folded FMAs + 4x4x1 MFMA", 5: "wavefront-per-subdomain, dense 16x16 element matrix on MFMA (v_mfma_f32_16x16x4_f32)"}.get(info["kernel"], str(info["kernel"])),
-            "sharding": f"{world} contiguous subdomain ranges, all-reduce of the trace vector per step" if world > 1 else "single GPU",
+            "sharding": {"none": "single GPU",
+                         "allreduce": f"{world} contiguous subdomain ranges, replicated trace vectors, one RCCL all-reduce of the trace vector per step",
+                         "neighbour": f"{world} contiguous subdomain ranges, trace vectors partitioned by slot ownership, grouped RCCL "
+                                      f"send/recv of {sum(i.numel() for i in getattr(sh, 'send_idx', {}).values()) * 4 / 1024:.0f} KiB to "
+                                      f"{len(getattr(sh, 'send_idx', {}))} neighbour rank(s) per step (rank 0), all-reduce of each inner product"}[exchange]
+                        + (f" [{exchange_note}]" if exchange_note else ""),
             "setup_seconds": round(t_setup, 2),
             "finite": finite,
         },

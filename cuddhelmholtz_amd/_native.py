@@ -60,6 +60,7 @@ class DdhDesc(C.Structure):
 
 
 ACTION_CB = C.CFUNCTYPE(None, vp, vp, vp)
+REDUCE_CB = C.CFUNCTYPE(None, vp, vp, C.c_int, C.c_int)
 
 
 def _sig(name, restype, *argtypes):
@@ -193,6 +194,7 @@ _sig("cuddh_ddh_table", C.c_longlong, vp, cp, vp, ci)
 _sig("cuddh_gmres_f64", ci, ci, vp, vp, vp, vp, ci, ci, cd, ci, cd, C.POINTER(SolverResult), vp, vp)
 _sig("cuddh_gmres_ddh", ci, ci, vp, vp, vp, ci, ci, cd, ci, cd, C.POINTER(SolverResult), vp, vp)
 _sig("cuddh_gmres_callback", ci, ci, vp, ACTION_CB, vp, vp, ci, ci, ci, cd, ci, cd, C.POINTER(SolverResult), vp, vp)
+_sig("cuddh_gmres_callback_sharded", ci, ci, vp, ACTION_CB, vp, REDUCE_CB, vp, vp, ci, ci, ci, cd, ci, cd, C.POINTER(SolverResult), vp, vp)
 
 
 def last_error() -> str:

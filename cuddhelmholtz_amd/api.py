@@ -395,10 +395,17 @@ class DDH:
         N.check_capi(lib.cuddh_ddh_local_solution(self._h, d0, d1, _ptr(lam), _ptr(f), _ptr(u), int(zero_u)), "DDH.local_solution")
 
 
-def gmres(n: int, x, A, b, m: int, maxit: int, tol: float = 1e-6, verbose: int = 0, max_seconds: float = 6 * 60 * 60, Precond=None) -> SolverOut:
+def gmres(n: int, x, A, b, m: int, maxit: int, tol: float = 1e-6, verbose: int = 0, max_seconds: float = 6 * 60 * 60, Precond=None,
+          reduce=None) -> SolverOut:
     """Restarted GMRES (reference include/gmres.hpp:33-36).  A: an operator of this module, a DDH,
-    or a Python callable `A(x, y)` acting on device tensors of x's dtype."""
+    or a Python callable `A(x, y)` acting on device tensors of x's dtype.
+
+    reduce (only with a callable A): `reduce(t)` sums the small device tensor `t` over all ranks in place
+    (torch.distributed.all_reduce) -- the vectors are then partitioned over the processes, see dist.py."""
     import torch
+
+    if reduce is not None and (isinstance(A, (DDH, _Operator)) or Precond is not None):
+        raise ValueError("gmres: reduce= needs a callable operator and no preconditioner")
 
     res = N.SolverResult()
     h_res = np.zeros(maxit + 2)
@@ -424,9 +431,20 @@ def gmres(n: int, x, A, b, m: int, maxit: int, tol: float = 1e-6, verbose: int =
             except Exception as e:  # noqa: BLE001 - must not propagate through C
                 errors.append(e)
 
+        def red(ctx, sp, count, f64):
+            try:
+                reduce(wrap(sp, count))
+            except Exception as e:  # noqa: BLE001
+                errors.append(e)
+
         cfun = N.ACTION_CB(cb)
-        N.check_capi(lib.cuddh_gmres_callback(n, _ptr(x), cfun, None, _ptr(b), int(is64), m, maxit, float(tol), verbose, float(max_seconds),
-                                              C.byref(res), _h(h_res), _h(h_time)), "gmres")
+        if reduce is None:
+            N.check_capi(lib.cuddh_gmres_callback(n, _ptr(x), cfun, None, _ptr(b), int(is64), m, maxit, float(tol), verbose,
+                                                  float(max_seconds), C.byref(res), _h(h_res), _h(h_time)), "gmres")
+        else:
+            rfun = N.REDUCE_CB(red)
+            N.check_capi(lib.cuddh_gmres_callback_sharded(n, _ptr(x), cfun, None, rfun, None, _ptr(b), int(is64), m, maxit, float(tol),
+                                                          verbose, float(max_seconds), C.byref(res), _h(h_res), _h(h_time)), "gmres")
         if errors:
             raise errors[0]
     return _solver_out(res, h_res, h_time)

@@ -36,6 +36,20 @@ namespace cuddh
                      int verbose = 0, double max_seconds = 6 * 60 * 60);
     solver_out gmres(int n, float *x, const SinglePrecisionOperator *A, const float *b, int m, int maxit,
                      float tol = 1e-4, int verbose = 0, double max_seconds = 6 * 60 * 60);
+
+    /// Vectors partitioned over processes (one per GPU): each rank passes its part of x and b (or a copy that is
+    /// zero outside the part it owns) and `fn` must sum `count` DEVICE scalars over all ranks in place, ordered on
+    /// stream() (an RCCL all-reduce).  Same iteration; every inner product is reduced before it is used, so all
+    /// ranks take identical decisions.  Not in the reference (single GPU).
+    struct ScalarReduce
+    {
+        void (*fn)(void *user, void *d_scalars, int count, int is_f64);
+        void *user;
+    };
+    solver_out gmres(int n, double *x, const Operator *A, const double *b, int m, int maxit, double tol, int verbose,
+                     double max_seconds, const ScalarReduce &reduce);
+    solver_out gmres(int n, float *x, const SinglePrecisionOperator *A, const float *b, int m, int maxit, float tol, int verbose,
+                     double max_seconds, const ScalarReduce &reduce);
 } // namespace cuddh
 
 #endif

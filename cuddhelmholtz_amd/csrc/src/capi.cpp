@@ -667,4 +667,27 @@ extern "C"
             fill_result(o, out, h_res, h_time);
         });
     }
+
+    int cuddh_gmres_callback_sharded(int n, void *x, cuddh_action_cb cb, void *ctx, cuddh_reduce_cb reduce, void *reduce_ctx,
+                                     const void *b, int is_f64, int m, int maxit, double tol, int verbose, double max_seconds,
+                                     cuddh_solver_result *out, double *h_res, double *h_time)
+    {
+        return guarded([&]
+        {
+            solver_out o;
+            const ScalarReduce red{reduce, reduce_ctx};
+            if (is_f64)
+            {
+                CallbackOp64 A(cb, ctx);
+                o = gmres(n, static_cast<double *>(x), &A, static_cast<const double *>(b), m, maxit, tol, verbose, max_seconds, red);
+            }
+            else
+            {
+                CallbackOp32 A(cb, ctx);
+                o = gmres(n, static_cast<float *>(x), &A, static_cast<const float *>(b), m, maxit, static_cast<float>(tol), verbose,
+                          max_seconds, red);
+            }
+            fill_result(o, out, h_res, h_time);
+        });
+    }
 }

@@ -17,12 +17,8 @@ namespace cuddh
         // ---- scalar-type dispatch onto the C ABI
         inline int k_dot(int n, const double *x, const double *y, double *r, void *ws) { return cuddh_hip_dot_f64(n, x, y, r, ws, stream()); }
         inline int k_dot(int n, const float *x, const float *y, float *r, void *ws) { return cuddh_hip_dot_f32(n, x, y, r, ws, stream()); }
-        inline int k_nrm2(int n, const double *x, double *r, void *ws) { return cuddh_hip_nrm2_f64(n, x, r, ws, stream()); }
-        inline int k_nrm2(int n, const float *x, float *r, void *ws) { return cuddh_hip_nrm2_f32(n, x, r, ws, stream()); }
         inline int k_axpby_dev(int n, double sa, const double *a, const double *x, double b, double *y) { return cuddh_hip_axpby_dev_f64(n, sa, a, x, b, y, stream()); }
         inline int k_axpby_dev(int n, float sa, const float *a, const float *x, float b, float *y) { return cuddh_hip_axpby_dev_f32(n, sa, a, x, b, y, stream()); }
-        inline int k_scal_inv_dev(int n, const double *a, double *x) { return cuddh_hip_scal_inv_dev_f64(n, a, x, stream()); }
-        inline int k_scal_inv_dev(int n, const float *a, float *x) { return cuddh_hip_scal_inv_dev_f32(n, a, x, stream()); }
         inline int k_mgs_stage(int n, double *w, const double *vp, const double *vn, const double *pi, double *po, double *h) { return cuddh_hip_mgs_stage_f64(n, w, vp, vn, pi, po, h, stream()); }
         inline int k_mgs_stage(int n, float *w, const float *vp, const float *vn, const float *pi, float *po, float *h) { return cuddh_hip_mgs_stage_f32(n, w, vp, vn, pi, po, h, stream()); }
         inline int k_mgs_finish(int n, double *w, const double *pi, double *h) { return cuddh_hip_mgs_finish_f64(n, w, pi, h, stream()); }
@@ -84,13 +80,12 @@ namespace cuddh
 
         template <typename scalar, typename Op>
         solver_out arnoldi_restarted(int n, scalar *x, const Op *A, const scalar *b, int m, int maxit, scalar tol, int verbose,
-                                     double max_seconds)
+                                     double max_seconds, const ScalarReduce *red = nullptr)
         {
             using clock = std::chrono::high_resolution_clock;
             const scalar one = 1, zero = 0;
             const int m1 = m + 1;
-
-            const scalar bnrm = norm(n, b);
+            constexpr int is_f64 = sizeof(scalar) == 8;
 
             HostDeviceArray<scalar> r_store(n), V_store(n * m1), col_store(m1 + 1);
             scalar *r = r_store.device_write();
@@ -105,6 +100,21 @@ namespace cuddh
                 ~Guard() { cuddh_hip_free(p); }
             } guard{ws};
 
+            // 2-norm; with partitioned vectors the sum of squares is reduced over the ranks first
+            auto norm_of = [&](const scalar *v) -> scalar
+            {
+                if (!red)
+                    return norm(n, v);
+                scalar ss = 0;
+                detail::check_hip(k_dot(n, v, v, dcol, ws), "gmres norm");
+                red->fn(red->user, dcol, 1, is_f64);
+                detail::check_hip(cuddh_hip_stream_sync(stream()), "gmres sync");
+                detail::check_hip(cuddh_hip_copy_d2h(&ss, dcol, sizeof(scalar)), "gmres norm copy");
+                return std::sqrt(ss);
+            };
+
+            const scalar bnrm = norm_of(b);
+
             std::vector<scalar> H(static_cast<std::size_t>(m1) * m, 0), cs(m, 0), sn(m, 0), eta(m1, 0);
 
             solver_out out;
@@ -117,7 +127,7 @@ namespace cuddh
             A->action(x, r);
             out.num_matvec++;
             axpby(n, one, b, -one, r); // r = b - A x
-            scalar r_nrm = norm(n, r);
+            scalar r_nrm = norm_of(r);
 
             out.res_norm.push_back(static_cast<double>(r_nrm));
             out.time.push_back(0.0);
@@ -156,6 +166,20 @@ namespace cuddh
                     // on v_{j-1} and leaves the partial sums of <w, v_j> (the last one <w, w>) for the next stage, so one
                     // launch per basis vector does what dot + reduce + axpy did; coefficients stay on the device.
                     // On breakdown (norm == 0) v_{k+1} becomes non-finite but is never used.
+                    if (red)
+                    {
+                        // partitioned vectors: every coefficient is summed over the ranks before it is applied
+                        for (int j = 0; j < k1; ++j)
+                        {
+                            const scalar *vj = V + static_cast<std::size_t>(j) * n;
+                            detail::check_hip(k_dot(n, vk1, vj, dcol + j, ws), "gmres dot");
+                            red->fn(red->user, dcol + j, 1, is_f64);
+                            detail::check_hip(k_axpby_dev(n, -one, dcol + j, vj, one, vk1), "gmres projection");
+                        }
+                        detail::check_hip(k_dot(n, vk1, vk1, dcol + k1, ws), "gmres dot");
+                        red->fn(red->user, dcol + k1, 1, is_f64);
+                    }
+                    else
                     {
                         scalar *pa = static_cast<scalar *>(ws), *pb = pa + cuddh_hip_reduce_ws_bytes() / (2 * sizeof(double));
                         detail::check_hip(k_mgs_stage(n, vk1, static_cast<const scalar *>(nullptr), V, pa, pa, dcol), "gmres mgs");
@@ -172,6 +196,12 @@ namespace cuddh
                     scalar *h = H.data() + static_cast<std::size_t>(m1) * k;
                     detail::check_hip(cuddh_hip_stream_sync(stream()), "gmres sync");
                     detail::check_hip(cuddh_hip_copy_d2h(h, dcol, sizeof(scalar) * (k1 + 1)), "gmres column copy");
+                    if (red)
+                    {
+                        h[k1] = std::sqrt(h[k1]); // the reduced sum of squares
+                        if (h[k1] != zero)
+                            scal(n, one / h[k1], vk1);
+                    }
 
                     if (h[k1] == zero)
                         break;
@@ -191,7 +221,7 @@ namespace cuddh
                 A->action(x, r);
                 out.num_matvec++;
                 axpby(n, one, b, -one, r);
-                r_nrm = norm(n, r);
+                r_nrm = norm_of(r);
 
                 out.res_norm.push_back(static_cast<double>(r_nrm));
                 const double elapsed = std::chrono::duration<double>(clock::now() - t0).count();
@@ -253,5 +283,17 @@ namespace cuddh
                      int verbose, double max_seconds)
     {
         return arnoldi_restarted<float>(n, x, A, b, m, maxit, tol, verbose, max_seconds);
+    }
+
+    solver_out gmres(int n, double *x, const Operator *A, const double *b, int m, int maxit, double tol, int verbose,
+                     double max_seconds, const ScalarReduce &reduce)
+    {
+        return arnoldi_restarted<double>(n, x, A, b, m, maxit, tol, verbose, max_seconds, reduce.fn ? &reduce : nullptr);
+    }
+
+    solver_out gmres(int n, float *x, const SinglePrecisionOperator *A, const float *b, int m, int maxit, float tol, int verbose,
+                     double max_seconds, const ScalarReduce &reduce)
+    {
+        return arnoldi_restarted<float>(n, x, A, b, m, maxit, tol, verbose, max_seconds, reduce.fn ? &reduce : nullptr);
     }
 } // namespace cuddh

@@ -130,6 +130,12 @@ int cuddh_gmres_ddh(int n, void *x, void *ddh, const void *b, int m, int maxit, 
 typedef void (*cuddh_action_cb)(void *ctx, const void *x, void *y);
 int cuddh_gmres_callback(int n, void *x, cuddh_action_cb cb, void *ctx, const void *b, int is_f64, int m, int maxit, double tol,
                          int verbose, double max_seconds, cuddh_solver_result *out, double *h_res, double *h_time);
+/* the same with vectors partitioned over processes (one per GPU): reduce(ctx, d_scalars, count, is_f64) must sum
+ * `count` DEVICE scalars over all ranks in place, ordered on the library stream (an RCCL all-reduce) */
+typedef void (*cuddh_reduce_cb)(void *ctx, void *d_scalars, int count, int is_f64);
+int cuddh_gmres_callback_sharded(int n, void *x, cuddh_action_cb cb, void *ctx, cuddh_reduce_cb reduce, void *reduce_ctx,
+                                 const void *b, int is_f64, int m, int maxit, double tol, int verbose, double max_seconds,
+                                 cuddh_solver_result *out, double *h_res, double *h_time);
 
 #ifdef __cplusplus
 }

@@ -304,16 +304,19 @@ class DDH:
 
 
 # ------------------------------------------------------------------ GMRES
-def gmres(A, b, x0=None, m=20, maxit=100, tol=1e-6, dtype=np.float64):
-    """source/gmres.cpp:91-235 with numpy vectors of `dtype`; A(x) -> A x.  Returns (x, info)."""
+def gmres(A, b, x0=None, m=20, maxit=100, tol=1e-6, dtype=np.float64, allreduce=None):
+    """source/gmres.cpp:91-235 with numpy vectors of `dtype`; A(x) -> A x.  Returns (x, info).
+    allreduce (tests of the multi-process host logic only): sums a scalar over the ranks when the vectors are
+    partitioned; every inner product then goes through it."""
     T = dtype
     n = len(b)
     b = np.asarray(b, dtype=T)
     x = np.zeros(n, dtype=T) if x0 is None else np.array(x0, dtype=T)
     one = T(1)
+    red = (lambda v: v) if allreduce is None else allreduce
 
     def nrm(v):
-        return T(math.sqrt(float(np.dot(v, v))))
+        return T(math.sqrt(float(red(np.dot(v, v)))))
 
     bnrm = nrm(b)
     m1 = m + 1
@@ -340,7 +343,7 @@ def gmres(A, b, x0=None, m=20, maxit=100, tol=1e-6, dtype=np.float64):
             w = np.asarray(A(V[:, k]), dtype=T)
             info["num_matvec"] += 1
             for j in range(k1):
-                H[j, k] = T(np.dot(w, V[:, j]))
+                H[j, k] = T(red(np.dot(w, V[:, j])))
                 w = w - H[j, k] * V[:, j]
             H[k1, k] = nrm(w)
             if H[k1, k] == 0:

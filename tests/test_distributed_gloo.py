@@ -12,7 +12,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 import oracle
-from cuddhelmholtz_amd.dist import ShardedDDH, partition
+from cuddhelmholtz_amd.dist import NeighbourShardedDDH, ShardedDDH, TraceExchange, partition
 
 
 class OracleEngine:
@@ -30,6 +30,14 @@ class OracleEngine:
         if zero_u:
             u.zero_()
         u += torch.from_numpy(y)
+
+    # what NeighbourShardedDDH asks of an engine
+    def table(self, name):
+        assert name == "B"
+        return np.asarray(self.O.t.B, dtype=np.int32).ravel(order="F")
+
+    def info(self):
+        return {"mx_fdof": int(self.O.t.mx_fdof), "n_lambda": int(self.O.t.n_lambda)}
 
 
 def build_case():
@@ -101,3 +109,94 @@ def test_two_ranks_reproduce_one_rank(tmp_path):
         # y receives floating point sums at nodes shared by subdomains of different ranks: order differs
         assert torch.allclose(got["u"], single[2], rtol=1e-13, atol=1e-15)
         assert got["nmv"] == single[3]
+
+
+# ------------------------------------------------------------------ partitioned vectors + neighbour exchange
+def build_case16():
+    nx, nb = 16, 4
+    omega = 2 * math.pi * nx / 10
+    d = oracle.Discretization(oracle.Mesh.uniform_rect(nx, -1.0, 1.0, nx, -1.0, 1.0), nb)
+    h_a = d.nodal(oracle.alpha_disk)
+    f = np.concatenate([oracle.linear_functional(d, oracle.gaussians(omega)), np.zeros(d.ndof)])
+    O = oracle.DDH(d, nx, nx, omega, h_a, np.float64)
+    return O, torch.from_numpy(f), d.ndof
+
+
+def solve_partitioned(sh, O, f, ndof):
+    n = O.size
+    b = torch.zeros(n, dtype=torch.float64)
+    sh.rhs(f, b)
+
+    def A(x):
+        y = torch.zeros(n, dtype=torch.float64)
+        sh.action(torch.from_numpy(np.ascontiguousarray(x)), y)
+        return y.numpy()
+
+    def allreduce(v):
+        t = torch.tensor([float(v)], dtype=torch.float64)
+        sh.reduce(t)
+        return float(t[0])
+
+    lam, info = oracle.gmres(A, b.numpy(), m=10, maxit=3, tol=1e-12, allreduce=allreduce)
+    lam = torch.from_numpy(lam)
+    u = torch.zeros(2 * ndof, dtype=torch.float64)
+    sh.postprocess(lam, f, u)
+    # every vector is zero outside the entries this rank owns
+    mask = torch.ones(n, dtype=torch.bool)
+    mask[sh.owned_idx] = False
+    assert not bool(b[mask].any()) and not bool(lam[mask].any())
+    return sh.full(b), sh.full(lam), u, info["num_matvec"]
+
+
+def worker_neighbour(rank, world, port, out_dir, overlap):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        O, f, ndof = build_case16()
+        sh = NeighbourShardedDDH(OracleEngine(O), O.t.n_domains, rank, world, overlap=overlap)
+        b, lam, u, nmv = solve_partitioned(sh, O, f, ndof)
+        torch.save({"b": b, "lam": lam, "u": u, "nmv": nmv}, os.path.join(out_dir, f"rank{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_trace_exchange_tables():
+    """ownership is a partition of the touched slots; send and receive lists of two ranks mirror each other;
+    boundary + interior ranges tile a rank's subdomains."""
+    O, _, _ = build_case16()
+    t = O.t
+    B = np.asarray(t.B, dtype=np.int32).ravel(order="F")
+    for world in (1, 2, 3, 5):
+        ex = [TraceExchange(B, t.n_domains, t.mx_fdof, t.n_lambda, r, world) for r in range(world)]
+        owned = np.concatenate([e.owned_slots for e in ex])
+        assert np.unique(owned).size == owned.size
+        touched = np.unique(np.asarray(t.B)[np.asarray(t.B) >= 0])
+        assert np.array_equal(np.sort(owned), touched)
+        assert t.n_lambda - touched.size == t.orphan_slots // 2
+        for r in range(world):
+            for s in range(world):
+                if r != s:
+                    a = ex[r].send_slots.get(s, np.zeros(0, dtype=np.int64))
+                    b = ex[s].recv_slots.get(r, np.zeros(0, dtype=np.int64))
+                    assert np.array_equal(a, b)
+            doms = sorted(d for a, b in ex[r].boundary_ranges + ex[r].interior_ranges for d in range(a, b))
+            assert doms == list(range(ex[r].d0, ex[r].d1))
+            if world > 1:
+                assert ex[r].boundary_ranges, "every rank of a connected block grid feeds a neighbour"
+        if world == 2:  # 4x4 blocks split into two strips of two block rows: one block row feeds the other rank
+            assert ex[0].boundary_ranges == [(4, 8)] and ex[1].boundary_ranges == [(8, 12)]
+
+
+@pytest.mark.parametrize("world,overlap", [(2, False), (3, True)])
+def test_neighbour_exchange_reproduces_one_rank(tmp_path, world, overlap):
+    O, f, ndof = build_case16()
+    single = solve(ShardedDDH(OracleEngine(O), O.t.n_domains), O, f, ndof)
+    mp.spawn(worker_neighbour, args=(world, free_port(), str(tmp_path), overlap), nprocs=world, join=True)
+    for r in range(world):
+        got = torch.load(os.path.join(tmp_path, f"rank{r}.pt"), weights_only=True)
+        assert torch.equal(got["b"], single[0])  # traces are copied, never summed: bitwise
+        # inner products are summed rank by rank: same iteration to rounding
+        assert got["nmv"] == single[3]
+        assert torch.allclose(got["lam"], single[1], rtol=1e-10, atol=1e-13 * float(single[1].abs().max()))
+        assert torch.allclose(got["u"], single[2], rtol=1e-9, atol=1e-12 * float(single[2].abs().max()))

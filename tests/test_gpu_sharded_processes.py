@@ -1,0 +1,76 @@
+"""Two processes on the one GPU of the test box run the partitioned DDH (neighbour exchange of trace slots, GMRES
+with reduced inner products) with the real HIP engine and must reproduce the single-process solve.  The RCCL
+transport itself needs two GPUs; here the same host logic runs over gloo with host-staged payloads."""
+import os
+import socket
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+pytestmark = pytest.mark.gpu
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("precision,overlap", [("f64", False), ("f32", True)])
+def test_two_processes_neighbour_exchange(cuda, tmp_path, precision, overlap):
+    import torch
+
+    sys.path.insert(0, str(ROOT / "tests"))
+    import sharded_worker as W
+
+    import cuddhelmholtz_amd as cd
+
+    nx, nb, world = 32, 4, 2
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), WORLD_SIZE=str(world))
+    procs = [subprocess.Popen([sys.executable, str(ROOT / "tests" / "sharded_worker.py"), str(nx), str(nb), precision,
+                               "1" if overlap else "0", str(tmp_path)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    logs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)
+
+    dev, fem, F, f = W.problem(nx, nb, precision)
+    n = F.size()
+    b = torch.zeros(n, dtype=F.trace_dtype, device=dev)
+    lam = torch.zeros_like(b)
+    u = torch.zeros(2 * fem.size(), dtype=torch.float64, device=dev)
+    F.rhs(f, b)
+    out = cd.gmres(n, lam, F, b, 10, 3, 0.0)
+    F.postprocess(lam, f, u)
+    rel = lambda a, r: float((a - r).norm() / r.norm())  # noqa: E731
+    for r in range(world):
+        got = torch.load(tmp_path / f"rank{r}.pt", weights_only=True)
+        assert got["zero_outside"]
+        assert torch.equal(got["b"], b.cpu())  # traces are copied between ranks, never summed: bitwise
+        assert got["nmv"] == out.num_matvec
+        # inner products are summed in a different order, and the single-process path uses the fused MGS chain
+        assert rel(got["lam"].double(), lam.cpu().double()) < (1e-9 if precision == "f64" else 2e-3)
+        assert rel(got["u"], u.cpu()) < (1e-9 if precision == "f64" else 2e-3)
+        boundary, interior = got["ranges"]
+        assert boundary and interior
+
+
+def test_bench_two_rank_rehearsal(cuda):
+    """bench.py's N > 1 code path (partition, neighbour exchange chosen after its start-up cross-check against the
+    all-reduce assembly, reduced inner products, max-over-ranks timing, one JSON line from rank 0) with two ranks
+    sharing the GPU over gloo.  The printed rate is not a measurement."""
+    import json
+
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), str(ROOT / "bench.py"), "--gpus", "2", "--rehearse-gloo", "--nx", "64", "--steps", "3",
+           "--warmup", "1", "--no-roofline"]
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["scaling"] == "strong" and out["config"]["finite"]
+    assert "partitioned by slot ownership" in out["config"]["sharding"] and "fell back" not in out["config"]["sharding"]
+    assert "cpu_baseline" not in out  # N = 1 only
