@@ -398,6 +398,334 @@ namespace
         }
     }
 
+    // ---------------------------------------------------------------- wavefront per TWO subdomains (NB = 8, 2x2 elements)
+    // The reference's other supported shape (source/DDH.cpp:631-636).  lane = k + 8 * element + 32 * (subdomain of the
+    // pair); every lane owns the eight eta-nodes of its column, so eta contractions are 8x8 in-lane FMAs with scalar
+    // coefficients.  The xi contraction runs over the eight lanes of an octet: partner k^x for x = 1,2,3 is a DPP
+    // quad_perm operand, k^7 is row_half_mirror, and k^4, k^5, k^6 are quad_perms of the half-mirrored copy; the
+    // coefficient of partner x is the per-lane register D(k, k^x).  xi neighbours (ex 0|1) sit in adjacent lanes 7|8 of a
+    // 16-lane row (DPP row shifts), eta neighbours (ey 0|1) 16 lanes apart (one ds_bpermute pair per sweep).
+    constexpr int QP_XOR1 = 0xB1, QP_XOR2 = 0x4E, QP_XOR3 = 0x1B, ROW_HALF_MIRROR = 0x141;
+
+    // out[l] = sum_x c[x] * (in[l] of lane k^x of my octet)
+    template <typename Real>
+    __device__ inline void octet_contract(const Real (&in)[8], const Real (&c)[8], Real (&out)[8])
+    {
+#pragma unroll
+        for (int l = 0; l < 8; ++l)
+        {
+            const Real t = dpp_read<ROW_HALF_MIRROR>(in[l]);
+            Real s = c[0] * in[l];
+            s += c[1] * dpp_read<QP_XOR1>(in[l]);
+            s += c[2] * dpp_read<QP_XOR2>(in[l]);
+            s += c[3] * dpp_read<QP_XOR3>(in[l]);
+            s += c[7] * t;
+            s += c[6] * dpp_read<QP_XOR1>(t);
+            s += c[5] * dpp_read<QP_XOR2>(t);
+            s += c[4] * dpp_read<QP_XOR3>(t);
+            out[l] = s;
+        }
+    }
+
+    // fp32 form with the cross-lane reads folded into the FMAs: 36 VALU instructions per four nodes.  The half-mirrored
+    // copies are written first and read through DPP at least four instructions later (the hazard needs two).
+#define CUDDH_DPP_TAIL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+#define CUDDH_X1 " quad_perm:[1,0,3,2]" CUDDH_DPP_TAIL
+#define CUDDH_X2 " quad_perm:[2,3,0,1]" CUDDH_DPP_TAIL
+#define CUDDH_X3 " quad_perm:[3,2,1,0]" CUDDH_DPP_TAIL
+    __device__ inline void octet_contract4_asm(const float *in, const float (&c)[8], float *out)
+    {
+        float o0, o1, o2, o3, t0, t1, t2, t3;
+        asm volatile("s_nop 1\n\t"
+                     "v_mov_b32_dpp %4, %8 row_half_mirror" CUDDH_DPP_TAIL
+                     "v_mov_b32_dpp %5, %9 row_half_mirror" CUDDH_DPP_TAIL
+                     "v_mov_b32_dpp %6, %10 row_half_mirror" CUDDH_DPP_TAIL
+                     "v_mov_b32_dpp %7, %11 row_half_mirror" CUDDH_DPP_TAIL
+                     "v_mul_f32 %0, %8, %12\n\t"
+                     "v_mul_f32 %1, %9, %12\n\t"
+                     "v_mul_f32 %2, %10, %12\n\t"
+                     "v_mul_f32 %3, %11, %12\n\t"
+                     "v_fmac_f32_dpp %0, %8, %13" CUDDH_X1
+                     "v_fmac_f32_dpp %1, %9, %13" CUDDH_X1
+                     "v_fmac_f32_dpp %2, %10, %13" CUDDH_X1
+                     "v_fmac_f32_dpp %3, %11, %13" CUDDH_X1
+                     "v_fmac_f32_dpp %0, %8, %14" CUDDH_X2
+                     "v_fmac_f32_dpp %1, %9, %14" CUDDH_X2
+                     "v_fmac_f32_dpp %2, %10, %14" CUDDH_X2
+                     "v_fmac_f32_dpp %3, %11, %14" CUDDH_X2
+                     "v_fmac_f32_dpp %0, %8, %15" CUDDH_X3
+                     "v_fmac_f32_dpp %1, %9, %15" CUDDH_X3
+                     "v_fmac_f32_dpp %2, %10, %15" CUDDH_X3
+                     "v_fmac_f32_dpp %3, %11, %15" CUDDH_X3
+                     "v_fmac_f32 %0, %4, %19\n\t"
+                     "v_fmac_f32 %1, %5, %19\n\t"
+                     "v_fmac_f32 %2, %6, %19\n\t"
+                     "v_fmac_f32 %3, %7, %19\n\t"
+                     "v_fmac_f32_dpp %0, %4, %18" CUDDH_X1
+                     "v_fmac_f32_dpp %1, %5, %18" CUDDH_X1
+                     "v_fmac_f32_dpp %2, %6, %18" CUDDH_X1
+                     "v_fmac_f32_dpp %3, %7, %18" CUDDH_X1
+                     "v_fmac_f32_dpp %0, %4, %17" CUDDH_X2
+                     "v_fmac_f32_dpp %1, %5, %17" CUDDH_X2
+                     "v_fmac_f32_dpp %2, %6, %17" CUDDH_X2
+                     "v_fmac_f32_dpp %3, %7, %17" CUDDH_X2
+                     "v_fmac_f32_dpp %0, %4, %16" CUDDH_X3
+                     "v_fmac_f32_dpp %1, %5, %16" CUDDH_X3
+                     "v_fmac_f32_dpp %2, %6, %16" CUDDH_X3
+                     "v_fmac_f32_dpp %3, %7, %16" CUDDH_X3
+                     : "=&v"(o0), "=&v"(o1), "=&v"(o2), "=&v"(o3), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+                     : "v"(in[0]), "v"(in[1]), "v"(in[2]), "v"(in[3]), "v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]), "v"(c[4]), "v"(c[5]),
+                       "v"(c[6]), "v"(c[7]));
+        out[0] = o0;
+        out[1] = o1;
+        out[2] = o2;
+        out[3] = o3;
+    }
+#undef CUDDH_X1
+#undef CUDDH_X2
+#undef CUDDH_X3
+#undef CUDDH_DPP_TAIL
+
+    template <bool ASM, typename Real>
+    __device__ inline void octet_contract_any(const Real (&in)[8], const Real (&c)[8], Real (&out)[8])
+    {
+        if constexpr (ASM && sizeof(Real) == 4)
+        {
+            octet_contract4_asm(&in[0], c, &out[0]);
+            octet_contract4_asm(&in[4], c, &out[4]);
+        }
+        else
+            octet_contract(in, c, out);
+    }
+
+    template <bool ASM, typename Real>
+    __device__ inline void wave8_stiffness(const Real (&w)[8], Real (&z)[8], const Real (&gx)[8], const Real (&gy)[8], const Real (&gz)[8],
+                                           const Real (&Dk)[8], const Real (&DTk)[8], const Real *__restrict__ Dm, Real mR, Real mL,
+                                           Real mU, Real mD, int lane)
+    {
+        Real ux[8], uy[8];
+        // eta derivative uy(k,l) = sum_i D(l,i) u(k,i): in-lane, scalar coefficients
+#pragma unroll
+        for (int l = 0; l < 8; ++l)
+        {
+            Real s = Dm[l] * w[0];
+#pragma unroll
+            for (int i = 1; i < 8; ++i)
+                s += Dm[l + 8 * i] * w[i];
+            uy[l] = s;
+        }
+        // xi derivative ux(k,l) = sum_i D(k,i) u(i,l): over the octet
+        octet_contract_any<ASM>(w, Dk, ux);
+        Real f1[8], f2[8];
+#pragma unroll
+        for (int l = 0; l < 8; ++l)
+        {
+            f1[l] = gx[l] * ux[l] + gy[l] * uy[l];
+            f2[l] = gy[l] * ux[l] + gz[l] * uy[l];
+        }
+        // test functions: sum_i D(i,k) f1(i,l)  +  sum_i D(i,l) f2(k,i)
+        Real zz[8];
+        octet_contract_any<ASM>(f1, DTk, zz);
+#pragma unroll
+        for (int l = 0; l < 8; ++l)
+        {
+            Real s = zz[l];
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                s += Dm[i + 8 * l] * f2[i];
+            zz[l] = s;
+        }
+        // assembly across elements.  xi neighbours: column k==7 of ex==0 meets column k==0 of ex==1 (lanes 7|8 of a row)
+        if constexpr (ASM && sizeof(Real) == 4)
+        {
+            const float(&za)[4] = reinterpret_cast<const float(&)[4]>(zz[0]);
+            const float(&zb)[4] = reinterpret_cast<const float(&)[4]>(zz[4]);
+            float ra[4], rb[4];
+            row_neighbours_asm(za, mR, mL, ra);
+            row_neighbours_asm(zb, mR, mL, rb);
+#pragma unroll
+            for (int l = 0; l < 4; ++l)
+            {
+                z[l] = zz[l] + ra[l];
+                z[4 + l] = zz[4 + l] + rb[l];
+            }
+        }
+        else
+        {
+#pragma unroll
+            for (int l = 0; l < 8; ++l)
+            {
+                const Real from_right = dpp_read<ROW_SHL1>(zz[l]);
+                const Real from_left = dpp_read<ROW_SHR1>(zz[l]);
+                z[l] = zz[l] + (mR * from_right + mL * from_left);
+            }
+        }
+        // eta neighbours: node l==7 of ey==0 meets node l==0 of ey==1, 16 lanes up
+        {
+            const Real top = z[7], bottom = z[0];
+            const Real from_above = __shfl(bottom, (lane + 16) & 63, 64);
+            const Real from_below = __shfl(top, (lane + 48) & 63, 64);
+            z[7] = top + mU * from_above;
+            z[0] = bottom + mD * from_below;
+        }
+    }
+
+    template <typename Real, bool ASM>
+    __global__ void __launch_bounds__(256) ddh_wave8_kernel(DdhArgs<Real> A, const Real *__restrict__ Dmat, const Real *__restrict__ filt,
+                                                           const Real *__restrict__ cs, const Real *__restrict__ sn)
+    {
+        const int lane = threadIdx.x & 63;
+        const int s_first = A.dom_begin + 2 * (blockIdx.x * 4 + (threadIdx.x >> 6));
+        if (s_first >= A.dom_end)
+            return; // wave-uniform: the kernel has no barriers
+        const int sub = lane >> 5;
+        const bool valid = s_first + sub < A.dom_end;
+        const int s = valid ? s_first + sub : s_first; // a missing second subdomain recomputes the first, writes nothing
+
+        const int k = lane & 7, el = (lane >> 3) & 3, ex = el & 1, ey = el >> 1;
+        const int fdof = A.s_fdof[s];
+        const int *sI = A.sI + 256 * (size_t)s;
+        const size_t dbase = (size_t)A.mx_dof * s, fbase = (size_t)A.mx_fdof * s;
+
+        Real gx[8], gy[8], gz[8], invm[8], Hi[8], F[8], Gf[8];
+        Real p[8], q[8], u[8], v[8];
+#pragma unroll
+        for (int l = 0; l < 8; ++l)
+        {
+            const int node = k + 8 * (l + 8 * el);
+            const int d = sI[node];
+            const Real *g = A.G + 3 * ((size_t)node + 256 * (size_t)s);
+            gx[l] = g[0];
+            gy[l] = g[1];
+            gz[l] = g[2];
+            const Real ai = A.a[dbase + d], mi = A.m[dbase + d];
+            invm[l] = Real(1) / (ai * ai * mi);
+            Real f = 0, gg = 0, h = 0;
+            if (A.x)
+            {
+                const int gidx = A.gI[dbase + d];
+                f = static_cast<Real>(A.x[gidx]);
+                gg = static_cast<Real>(A.x[A.g_ndof + gidx]);
+            }
+            if (d < fdof)
+            {
+                h = A.H[fbase + d];
+                if (A.lambda)
+                {
+                    const int slot = A.B[d + (size_t)A.mx_fdof * (0 + 2 * (size_t)s)];
+                    if (slot >= 0)
+                    {
+                        f += h * A.lambda[slot];
+                        gg += h * A.lambda[A.n_lambda + slot];
+                    }
+                }
+                h *= ai;
+            }
+            F[l] = f;
+            Gf[l] = gg;
+            Hi[l] = h;
+            p[l] = q[l] = u[l] = v[l] = 0;
+        }
+
+        Real Dk[8], DTk[8];
+#pragma unroll
+        for (int x = 0; x < 8; ++x)
+        {
+            Dk[x] = Dmat[k + 8 * (k ^ x)];  // D(k, k^x)
+            DTk[x] = Dmat[(k ^ x) + 8 * k]; // D(k^x, k)
+        }
+        const Real mR = (k == 7 && ex == 0) ? Real(1) : Real(0);
+        const Real mL = (k == 0 && ex == 1) ? Real(1) : Real(0);
+        const Real mU = (ey == 0) ? Real(1) : Real(0);
+        const Real mD = (ey == 1) ? Real(1) : Real(0);
+
+        const Real dt = A.dt, half_dt = Real(0.5) * A.dt;
+        const int nt = A.nt;
+
+        for (int whit = 0; whit < WH_ITERS; ++whit)
+        {
+            {
+                const Real k0 = filt[0];
+#pragma unroll
+                for (int l = 0; l < 8; ++l)
+                {
+                    p[l] = u[l];
+                    q[l] = v[l];
+                    u[l] *= k0;
+                    v[l] *= k0;
+                }
+            }
+            for (int it = 1; it <= nt; ++it)
+            {
+                const Real c0 = cs[2 * it - 2], s0 = sn[2 * it - 2];
+                const Real c1 = cs[2 * it - 1], s1 = sn[2 * it - 1];
+                const Real kw = filt[it];
+                Real z[8], ph[8], qh[8];
+
+                wave8_stiffness<ASM>(p, z, gx, gy, gz, Dk, DTk, Dmat, mR, mL, mU, mD, lane);
+#pragma unroll
+                for (int l = 0; l < 8; ++l)
+                {
+                    const Real dq = ((z[l] - Hi[l] * q[l]) + c0 * F[l] + s0 * Gf[l]) * invm[l];
+                    ph[l] = p[l] - half_dt * q[l];
+                    qh[l] = q[l] + half_dt * dq;
+                    p[l] -= dt * qh[l];
+                }
+                wave8_stiffness<ASM>(ph, z, gx, gy, gz, Dk, DTk, Dmat, mR, mL, mU, mD, lane);
+#pragma unroll
+                for (int l = 0; l < 8; ++l)
+                {
+                    const Real dq = ((z[l] - Hi[l] * qh[l]) + c1 * F[l] + s1 * Gf[l]) * invm[l];
+                    q[l] += dt * dq;
+                    u[l] += kw * p[l];
+                    v[l] += kw * q[l];
+                }
+            }
+        }
+
+        if (!valid)
+            return;
+        const Real rw = Real(1) / A.omega;
+#pragma unroll
+        for (int l = 0; l < 8; ++l)
+        {
+            v[l] *= rw;
+            // every shared node is held by 2 or 4 (lane, l) pairs with identical values: the copy with
+            // the smallest element-node index writes
+            const bool owner = !(k == 0 && ex > 0) && !(l == 0 && ey > 0);
+            if (!owner)
+                continue;
+            const int d = sI[k + 8 * (l + 8 * el)];
+            if (A.y)
+            {
+                const int gidx = A.gI[dbase + d];
+                const Real M = A.m[dbase + d] * A.gmi[dbase + d];
+                atomic_add(A.y + gidx, static_cast<double>(M * u[l]));
+                atomic_add(A.y + A.g_ndof + gidx, static_cast<double>(M * v[l]));
+            }
+            if (A.update && d < fdof)
+            {
+                const int wslot = A.B[d + (size_t)A.mx_fdof * (1 + 2 * (size_t)s)];
+                if (wslot >= 0)
+                {
+                    Real lam = 0, mu = 0;
+                    if (A.lambda)
+                    {
+                        const int rslot = A.B[d + (size_t)A.mx_fdof * (0 + 2 * (size_t)s)];
+                        if (rslot >= 0)
+                        {
+                            lam = A.lambda[rslot];
+                            mu = A.lambda[A.n_lambda + rslot];
+                        }
+                    }
+                    const Real S = Real(2) * A.a[dbase + d] * A.omega;
+                    A.update[wslot] = -lam - S * v[l];
+                    A.update[A.n_lambda + wslot] = -mu + S * u[l];
+                }
+            }
+        }
+    }
+
     // ---------------------------------------------------------------- dense element matrix on the matrix cores (NB = 4, uniform geometry)
     // When every element of every subdomain has the same metric tensor (always the case on the uniform_rect
     // meshes DDH supports) the element-local part of a stiffness sweep is Z = K U with one 16x16 element matrix K
@@ -582,22 +910,25 @@ namespace
         }
     }
 
-    // structure check for the wave kernel: 169 dofs, xi/eta neighbours share exactly the expected nodes
+    // structure check for the wave kernels (NB nodes per direction, NEL x NEL elements, NB*NEL == 16): the expected
+    // number of dofs, and xi/eta neighbours share exactly the expected nodes
+    template <int NB, int NEL>
     __global__ void __launch_bounds__(256) ddh_wave_check_kernel(int n_domains, const int *__restrict__ s_dof, const int *__restrict__ sI,
                                                                  int *__restrict__ bad)
     {
+        constexpr int SIDE = NB * NEL - (NEL - 1), NDOF = SIDE * SIDE, NN = NB * NB;
         const int s = blockIdx.x, tid = threadIdx.x;
         if (s >= n_domains)
             return;
-        const int k = tid & 3, l = (tid >> 2) & 3, el = tid >> 4, ex = el & 3, ey = el >> 2;
+        const int k = tid % NB, l = (tid / NB) % NB, el = tid / NN, ex = el % NEL, ey = el / NEL;
         const int *I = sI + 256 * (size_t)s;
-        bool ok = I[tid] >= 0 && I[tid] < 169;
+        bool ok = I[tid] >= 0 && I[tid] < NDOF;
         if (tid == 0)
-            ok = ok && s_dof[s] == 169;
-        if (k == 3 && ex < 3)
-            ok = ok && I[tid] == I[0 + 4 * (l + 4 * (el + 1))];
-        if (l == 3 && ey < 3)
-            ok = ok && I[tid] == I[k + 4 * (0 + 4 * (el + 4))];
+            ok = ok && s_dof[s] == NDOF;
+        if (k == NB - 1 && ex < NEL - 1)
+            ok = ok && I[tid] == I[0 + NB * (l + NB * (el + 1))];
+        if (l == NB - 1 && ey < NEL - 1)
+            ok = ok && I[tid] == I[k + NB * (0 + NB * (el + NEL))];
         if (!ok)
             atomicExch(bad, 1);
     }
@@ -957,6 +1288,14 @@ namespace
                 return launch_status();
             }
         }
+        if (plan->kernel == 6)
+        {
+            const dim3 grid((n_local + 7) / 8), block(256); // four wavefronts per workgroup, two subdomains per wavefront
+            const Real *D = static_cast<const Real *>(d.D), *fl = static_cast<const Real *>(d.wh_filter);
+            const Real *cs = static_cast<const Real *>(d.cs), *sn = static_cast<const Real *>(d.sn);
+            hipLaunchKernelGGL((ddh_wave8_kernel<Real, sizeof(Real) == 4>), grid, block, 0, st, A, D, fl, cs, sn);
+            return launch_status();
+        }
         if (plan->kernel >= 2)
         {
             // kernels 3 and 4 exist in fp32 only; fp64 always takes the plain form
@@ -988,6 +1327,25 @@ namespace
         }
         return launch_status();
     }
+    // do all subdomains have the structured NEL x NEL element layout the wave kernels assume?  *bad = 0 if so
+    template <int NB, int NEL>
+    int run_structure_check(const cuddh_ddh_desc *desc, int *bad)
+    {
+        int *flag = nullptr;
+        hipError_t e = hipMalloc(&flag, sizeof(int));
+        if (e == hipSuccess)
+            e = hipMemset(flag, 0, sizeof(int));
+        *bad = 1;
+        if (e == hipSuccess)
+        {
+            hipLaunchKernelGGL((ddh_wave_check_kernel<NB, NEL>), dim3(desc->n_domains), dim3(256), 0, nullptr, desc->n_domains,
+                               desc->s_dof, desc->sI, flag);
+            e = hipMemcpy(bad, flag, sizeof(int), hipMemcpyDeviceToHost);
+        }
+        if (flag)
+            (void)hipFree(flag);
+        return static_cast<int>(e);
+    }
 } // namespace
 
 extern "C"
@@ -1009,7 +1367,7 @@ extern "C"
     int cuddh_hip_ddh_plan_create(cuddh_ddh_plan **out, const cuddh_ddh_desc *desc, int is_f64, int kernel)
     {
         *out = nullptr;
-        if (!desc || desc->nb < 2 || desc->nb > 10 || desc->nel1d < 1 || kernel < 0 || kernel > 5)
+        if (!desc || desc->nb < 2 || desc->nb > 10 || desc->nel1d < 1 || kernel < 0 || kernel > 6)
             return static_cast<int>(hipErrorInvalidValue);
         const int nodes = desc->nb * desc->nb * desc->nel1d * desc->nel1d;
         if (nodes > 256)
@@ -1022,30 +1380,37 @@ extern "C"
         p->kernel = 1;
 
         const bool wave_shape = (desc->nb == 4 && desc->nel1d == 4);
-        if (kernel >= 2 && !wave_shape)
+        const bool wave8_shape = (desc->nb == 8 && desc->nel1d == 2);
+        if ((kernel >= 2 && kernel <= 5 && !wave_shape) || (kernel == 6 && !wave8_shape))
         {
             delete p;
             return static_cast<int>(hipErrorInvalidValue);
         }
-        if (wave_shape && kernel != 1)
+        if (wave8_shape && kernel != 1)
         {
-            int *flag = nullptr;
-            hipError_t e = hipMalloc(&flag, sizeof(int));
-            if (e == hipSuccess)
-                e = hipMemset(flag, 0, sizeof(int));
             int bad = 1;
-            if (e == hipSuccess)
-            {
-                hipLaunchKernelGGL(ddh_wave_check_kernel, dim3(desc->n_domains), dim3(256), 0, nullptr, desc->n_domains, desc->s_dof,
-                                   desc->sI, flag);
-                e = hipMemcpy(&bad, flag, sizeof(int), hipMemcpyDeviceToHost);
-            }
-            if (flag)
-                (void)hipFree(flag);
-            if (e != hipSuccess)
+            const int e = run_structure_check<8, 2>(desc, &bad);
+            if (e)
             {
                 delete p;
-                return static_cast<int>(e);
+                return e;
+            }
+            if (!bad)
+                p->kernel = 6;
+            else if (kernel == 6)
+            {
+                delete p;
+                return static_cast<int>(hipErrorInvalidValue);
+            }
+        }
+        if (wave_shape && kernel != 1)
+        {
+            int bad = 1;
+            const int e = run_structure_check<4, 4>(desc, &bad);
+            if (e)
+            {
+                delete p;
+                return e;
             }
             if (!bad)
                 p->kernel = (kernel >= 2) ? kernel : 3; // auto prefers the folded-DPP form (fp64 runs the plain form either way)

@@ -213,10 +213,12 @@ typedef struct cuddh_ddh_plan cuddh_ddh_plan;
  *         4 = 3 with the in-lane contractions on the matrix pipe (v_mfma_f32_4x4x1_16b_f32, fp32),
  *         5 = one 16x16 element matrix applied to the 16 elements of a subdomain per sweep with four
  *             v_mfma_f32_16x16x4_f32 (fp32; needs the same metric tensor in every element, which
- *             plan_create verifies on the device; what auto picks when it applies). */
+ *             plan_create verifies on the device; what auto picks when it applies),
+ *         6 = n_basis == 8 (2x2 elements, the reference's other supported shape): one wavefront per TWO
+ *             subdomains, registers + DPP over the eight lanes of a column octet (what auto picks for nb == 8). */
 int cuddh_hip_ddh_plan_create(cuddh_ddh_plan **plan, const cuddh_ddh_desc *desc, int is_f64, int kernel);
 int cuddh_hip_ddh_plan_destroy(cuddh_ddh_plan *plan);
-/* which kernel the plan resolved to (1..5) */
+/* which kernel the plan resolved to (1..6) */
 int cuddh_hip_ddh_plan_kernel(const cuddh_ddh_plan *plan);
 
 /* source/DDH.cpp:111-321 (ddh_action + stiffness).  x: forcing [F;G] (2*g_ndof
