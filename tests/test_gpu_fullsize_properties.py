@@ -40,6 +40,18 @@ def test_operator_invariants_at_full_size(cuda, big):
     # symmetry: x2^T M x1 == x1^T M x2
     a, b = float(torch.dot(x2, y1)), float(torch.dot(x1, y2))
     assert abs(a - b) <= 1e-12 * abs(a)
+    # the patch-plan kernels have no atomics: bitwise reproducible; action(c, x, y) accumulates onto what action(x, y) wrote
+    S = cd.StiffnessMatrix(fem)
+    S.action(x1, y1)
+    S.action(x1, y2)
+    assert torch.equal(y1, y2)
+    scale = float(y1.abs().max())
+    S.action(-1.0, x1, y2)
+    assert float(y2.abs().max()) <= 1e-13 * scale
+    Mw.action(x1, y2)
+    Mw.action(2.0, x1, y1)  # y1 = S x1 + 2 M x1
+    S.action(-1.0, x1, y1)
+    assert float((y1 - 2.0 * y2).abs().max()) <= 1e-12 * scale
 
 
 def test_fused_helmholtz_linearity_symmetry_determinism_at_full_size(cuda, big):
@@ -67,7 +79,7 @@ def test_fused_helmholtz_linearity_symmetry_determinism_at_full_size(cuda, big):
     s1, s2 = float(torch.dot(z, Ax)), float(torch.dot(x, Az))
     assert abs(s1 - s2) <= 1e-11 * max(abs(s1), abs(s2))
     U = torch.empty_like(x)
-    A.action_unfused(x, U)  # the per-class kernels with fp64 atomics
+    A.action_unfused(x, U)  # the composite of the separate operators (examples/Helmholtz.hpp:28-56)
     assert float(torch.linalg.norm(U - Ax) / torch.linalg.norm(Ax)) < 1e-13
 
 
@@ -102,3 +114,37 @@ def test_ddh_properties_at_full_size(cuda, big):
     sh.action(lam, y4)
     assert torch.equal(y4, y1)
     assert bool(torch.isfinite(y1).all())
+
+    # the 8-rank neighbour exchange replayed in one process: every rank sees only the entries it owns, solves its
+    # range, and the messages are delivered by hand; the assembled traces must be bitwise the single-rank ones
+    from cuddhelmholtz_amd.dist import NeighbourShardedDDH
+
+    world = 8
+    ranks = [NeighbourShardedDDH(F, 65536, r, world, device=cuda, dry_run=True) for r in range(world)]
+    owned = torch.cat([r.owned_idx for r in ranks])
+    assert owned.numel() == torch.unique(owned).numel()  # ownership is a partition ...
+    assert not bool(lam.new_ones(lam.numel()).index_fill_(0, owned, 0).mul(upd_whole).any())  # ... of everything that is written
+    outs = []
+    for r in ranks:
+        lam_r = torch.zeros_like(lam)
+        lam_r[r.owned_idx] = lam[r.owned_idx]
+        out_r = torch.zeros_like(lam)
+        F.local_traces(r.d0, r.d1, None, lam_r, out_r)
+        outs.append(out_r)
+        assert len(r.send_idx) == (1 if r.rank in (0, world - 1) else 2)  # strips of block rows: at most two neighbours
+        # per neighbour: 256 subdomain edges x 13 dofs, minus 2 slots lost to the cross-point quirk at each of the 255
+        # interior cross points, times (lambda, mu): 5636 floats = 22 KiB
+        assert all(i.numel() == 2 * (256 * 13 - 2 * 255) for i in r.send_idx.values())
+    for r in ranks:
+        for s_rank, idx in r.send_idx.items():
+            dst = ranks[s_rank].recv_idx[r.rank]
+            assert torch.equal(dst, idx)
+            outs[s_rank][dst] = outs[r.rank][idx]
+    for r in ranks:
+        for idx in r.send_idx.values():
+            outs[r.rank][idx] = 0
+    for r, out_r in zip(ranks, outs):
+        mask = torch.ones(lam.numel(), dtype=torch.bool, device=cuda)
+        mask[r.owned_idx] = False
+        assert not bool(out_r[mask].any())  # zero outside the owned entries
+    assert torch.equal(torch.stack(outs).sum(0), upd_whole)
