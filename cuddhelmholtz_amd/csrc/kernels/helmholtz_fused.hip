@@ -20,7 +20,6 @@
 // The apply is therefore bitwise reproducible and needs no zero-fill of y.
 #include <algorithm>
 #include <cstdint>
-#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -53,8 +52,6 @@ struct cuddh_helmholtz_plan
     int *shared_dof = nullptr, *shared_off = nullptr, *shared_slots = nullptr;
     double *part = nullptr; // [2][n_slots]
     size_t bytes_alg = 0, bytes_actual = 0;
-    int prefetch = 0; // kernel variant (tuning knob, env CUDDH_HELM_PREFETCH)
-    int waves = 1;    // 1: one wavefront per patch (default; measured faster), 3: role-specialised wavefronts (env CUDDH_HELM_WAVES)
 };
 
 namespace
@@ -74,10 +71,10 @@ namespace
         double *y, *part;
     };
 
-    // MODE: how the metric slices reach the registers -- 0 load-then-use, 1 software pipelined (second register set),
-    // 2 split between the two half-waves and exchanged with ds_bpermute (see the element phase)
-    template <int NB, int NQS, int NQM, int MODE>
-    __global__ void __launch_bounds__(64, (NB >= 5 ? 2 : (MODE >= 1 ? 3 : 4))) helm_patch_kernel(HelmArgs A, const double *__restrict__ PS, const double *__restrict__ DS,
+    // Variants measured and dropped: software-pipelined slice loads, slices split between the half-waves
+    // and exchanged with ds_bpermute, three role-specialised wavefronts per patch, touch-prefetch of the metric block.
+    template <int NB, int NQS, int NQM>
+    __global__ void __launch_bounds__(64, (NB >= 5 ? 2 : 4)) helm_patch_kernel(HelmArgs A, const double *__restrict__ PS, const double *__restrict__ DS,
                                                            const double *__restrict__ PM, const double *__restrict__ PF)
     {
         constexpr int NN = NB * NB;
@@ -249,77 +246,6 @@ namespace
                     out[k + NB * l] += PM[q + NQM * k] * t[l];
         };
 
-        if constexpr (MODE == 2)
-        {
-            // The two half-waves (u lanes / v lanes) need the same metric values.  Instead of both fetching the same
-            // slice, the lower half fetches slice 2j and the upper half slice 2j+1, and each value is handed to the
-            // other half with ds_bpermute when its slice is processed: twice the bytes in flight per register.
-#pragma unroll 1
-            for (int qp = 0; qp < (NQS + 1) / 2; ++qp)
-            {
-                const int q0 = 2 * qp, q1 = (2 * qp + 1 < NQS) ? 2 * qp + 1 : q0;
-                double R[3 * NQS], g[3 * NQS];
-                load_stiff(comp ? q1 : q0, R);
-#pragma unroll
-                for (int j = 0; j < 3 * NQS; ++j)
-                    g[j] = __shfl(R[j], le, 64);
-                stiff_slice(q0, g);
-                if (2 * qp + 1 < NQS)
-                {
-#pragma unroll
-                    for (int j = 0; j < 3 * NQS; ++j)
-                        g[j] = __shfl(R[j], le + 32, 64);
-                    stiff_slice(q1, g);
-                }
-            }
-#pragma unroll 1
-            for (int qp = 0; qp < (NQM + 1) / 2; ++qp)
-            {
-                const int q0 = 2 * qp, q1 = (2 * qp + 1 < NQM) ? 2 * qp + 1 : q0;
-                double R[NQM], am[NQM];
-                load_mass(comp ? q1 : q0, R);
-#pragma unroll
-                for (int j = 0; j < NQM; ++j)
-                    am[j] = __shfl(R[j], le, 64);
-                mass_slice(q0, am);
-                if (2 * qp + 1 < NQM)
-                {
-#pragma unroll
-                    for (int j = 0; j < NQM; ++j)
-                        am[j] = __shfl(R[j], le + 32, 64);
-                    mass_slice(q1, am);
-                }
-            }
-        }
-        else if constexpr (MODE == 1)
-        {
-            // slice q+1 is requested before slice q is consumed (second register set, one wave per SIMD fewer)
-            double gcur[3 * NQS];
-            load_stiff(0, gcur);
-#pragma unroll 1
-            for (int q = 0; q < NQS; ++q)
-            {
-                double gnext[3 * NQS];
-                load_stiff((q + 1 < NQS) ? q + 1 : q, gnext); // the last iteration re-requests its own slice: a cache hit
-                stiff_slice(q, gcur);
-#pragma unroll
-                for (int j = 0; j < 3 * NQS; ++j)
-                    gcur[j] = gnext[j];
-            }
-            double acur[NQM];
-            load_mass(0, acur);
-#pragma unroll 1
-            for (int q = 0; q < NQM; ++q)
-            {
-                double anext[NQM];
-                load_mass((q + 1 < NQM) ? q + 1 : q, anext);
-                mass_slice(q, acur);
-#pragma unroll
-                for (int j = 0; j < NQM; ++j)
-                    acur[j] = anext[j];
-            }
-        }
-        else
         {
             // q stays a real loop: unrolling it lets the scheduler hoist every load of the element and exhausts the VGPRs
 #pragma unroll 1
@@ -443,284 +369,6 @@ namespace
         }
     }
 
-    // ---------------------------------------------------------------- three role-specialised wavefronts per patch
-    // Same patch, same data layout, but the serial chain of a wavefront is cut in three: wave 0 applies the stiffness
-    // operator (NQS slices), waves 1 and 2 one half of the mass operator's slices each, all from the same LDS copy of x.
-    // Each wave accumulates into its own LDS copy of y (colour phases need no workgroup barrier inside one wave: a
-    // wave's LDS operations complete in order); the copies are summed when the patch is written out.  Three times as
-    // many wavefronts are in flight per patch, which is what small meshes (few patches per CU) and the DRAM queues need.
-    template <int NB, int NQS, int NQM>
-    __global__ void __launch_bounds__(192) helm_patch3_kernel(HelmArgs A, const double *__restrict__ PS, const double *__restrict__ DS,
-                                                              const double *__restrict__ PM, const double *__restrict__ PF)
-    {
-        constexpr int NN = NB * NB, NP = (NN + 1) / 2;
-        extern __shared__ double lds[];
-        const int patch = (blockIdx.x & 7) * A.xcd_chunk + (blockIdx.x >> 3);
-        if (patch >= A.n_patches)
-            return; // whole workgroup
-        const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-        const int comp = lane >> 5, le = lane & 31;
-        const int ML = A.max_loc;
-        double *xs = lds;                              // [2][ML]
-        double *ysw = lds + 2 * ML + wave * 2 * ML;    // this wave's [2][ML]
-
-        const int off = A.dof_off[patch];
-        const int nloc = A.dof_off[patch + 1] - off;
-        const int *dofs = A.dof_list + off;
-
-        for (int base = 0; base < nloc; base += 384)
-        {
-            int gi[2];
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-                gi[j] = dofs[min(base + 192 * j + tid, nloc - 1)];
-            double xu[2], xv[2];
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-            {
-                xu[j] = A.x[gi[j]];
-                xv[j] = A.x[A.ndof + gi[j]];
-            }
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-            {
-                const int i = base + 192 * j + tid;
-                if (i < nloc)
-                {
-                    xs[i] = xu[j];
-                    xs[ML + i] = xv[j];
-#pragma unroll
-                    for (int w = 0; w < 3; ++w)
-                    {
-                        lds[(2 + 2 * w) * ML + i] = 0.0;
-                        lds[(3 + 2 * w) * ML + i] = 0.0;
-                    }
-                }
-            }
-        }
-        __syncthreads();
-
-        const bool active = le < A.patch_nel[patch];
-        const uint32_t *li = A.lidx + ((size_t)patch * NP) * PE + le;
-        const double *xc = xs + comp * ML;
-        uint32_t lpk[NP];
-#pragma unroll
-        for (int j = 0; j < NP; ++j)
-            lpk[j] = li[j * PE];
-        auto lix_of = [&](int n) -> int { return (n & 1) ? static_cast<int>(lpk[n >> 1] >> 16) : static_cast<int>(lpk[n >> 1] & 0xFFFFu); };
-        const double keep = active ? 1.0 : 0.0;
-        double u[NN], out[NN];
-#pragma unroll
-        for (int n = 0; n < NN; ++n)
-        {
-            u[n] = keep * xc[lix_of(n)];
-            out[n] = 0.0;
-        }
-
-        if (wave == 0)
-        {
-            const double *Gp = A.Gp + (size_t)patch * 3 * NQS * NQS * PE + le;
-#pragma unroll 1
-            for (int q = 0; q < NQS; ++q)
-            {
-                double g[3 * NQS];
-#pragma unroll
-                for (int j = 0; j < 3 * NQS; ++j)
-                    g[j] = Gp[(q * 3 * NQS + j) * PE]; // [q][c][r]: j = c * NQS + r
-                double pu[NB], du[NB], t0[NB], t1[NB];
-#pragma unroll
-                for (int l = 0; l < NB; ++l)
-                {
-                    double a = 0.0, b = 0.0;
-#pragma unroll
-                    for (int k = 0; k < NB; ++k)
-                    {
-                        a += PS[q + NQS * k] * u[k + NB * l];
-                        b += DS[q + NQS * k] * u[k + NB * l];
-                    }
-                    pu[l] = a;
-                    du[l] = b;
-                    t0[l] = 0.0;
-                    t1[l] = 0.0;
-                }
-#pragma unroll
-                for (int r = 0; r < NQS; ++r)
-                {
-                    const double ga = g[r], gb = g[NQS + r], gc = g[2 * NQS + r];
-                    double dx = 0.0, dy = 0.0;
-#pragma unroll
-                    for (int l = 0; l < NB; ++l)
-                    {
-                        dx += PS[r + NQS * l] * du[l];
-                        dy += DS[r + NQS * l] * pu[l];
-                    }
-                    const double f0 = ga * dx + gb * dy;
-                    const double f1 = gb * dx + gc * dy;
-#pragma unroll
-                    for (int l = 0; l < NB; ++l)
-                    {
-                        t0[l] += PS[r + NQS * l] * f0;
-                        t1[l] += DS[r + NQS * l] * f1;
-                    }
-                }
-#pragma unroll
-                for (int l = 0; l < NB; ++l)
-#pragma unroll
-                    for (int k = 0; k < NB; ++k)
-                        out[k + NB * l] += DS[q + NQS * k] * t0[l] + PS[q + NQS * k] * t1[l];
-            }
-        }
-        else
-        {
-            const double *ap = A.aMp + (size_t)patch * NQM * NQM * PE + le;
-            const double w2 = -A.omega * A.omega;
-            const int q_begin = (wave == 1) ? 0 : NQM / 2, q_end = (wave == 1) ? NQM / 2 : NQM;
-#pragma unroll 1
-            for (int q = q_begin; q < q_end; ++q)
-            {
-                double am[NQM];
-#pragma unroll
-                for (int r = 0; r < NQM; ++r)
-                    am[r] = ap[(q * NQM + r) * PE];
-                double pu[NB], t[NB];
-#pragma unroll
-                for (int l = 0; l < NB; ++l)
-                {
-                    double a = 0.0;
-#pragma unroll
-                    for (int k = 0; k < NB; ++k)
-                        a += PM[q + NQM * k] * u[k + NB * l];
-                    pu[l] = a;
-                    t[l] = 0.0;
-                }
-#pragma unroll
-                for (int r = 0; r < NQM; ++r)
-                {
-                    double val = 0.0;
-#pragma unroll
-                    for (int l = 0; l < NB; ++l)
-                        val += PM[r + NQM * l] * pu[l];
-                    val *= am[r] * w2;
-#pragma unroll
-                    for (int l = 0; l < NB; ++l)
-                        t[l] += PM[r + NQM * l] * val;
-                }
-#pragma unroll
-                for (int l = 0; l < NB; ++l)
-#pragma unroll
-                    for (int k = 0; k < NB; ++k)
-                        out[k + NB * l] += PM[q + NQM * k] * t[l];
-            }
-        }
-
-        // accumulate into this wave's copy; a colour's elements share no dof, phases are ordered by the in-order LDS queue
-        {
-            const double sgn = comp ? -1.0 : 1.0;
-            double *yc = ysw + comp * ML;
-            const int mycol = active ? A.colour[patch * PE + le] : -1;
-            for (int c = 0; c < A.ncol; ++c)
-            {
-                if (mycol == c)
-                {
-#pragma unroll
-                    for (int n = 0; n < NN; ++n)
-                        yc[lix_of(n)] += sgn * out[n];
-                }
-                __builtin_amdgcn_wave_barrier();
-            }
-        }
-
-        // boundary faces (wave 0 only):  Au -= w H v,  Av -= w H u
-        if (wave == 0)
-        {
-            const int f_begin = A.face_off[patch], nf = A.face_off[patch + 1] - f_begin;
-            const double *xo = xs + (1 - comp) * ML;
-            double *yc = ysw + comp * ML;
-            const int nqF = A.nqF;
-            for (int f0 = 0; f0 < nf; f0 += PE)
-            {
-                const int f = f0 + le;
-                double res[NB];
-                int fl[NB];
-                int fc = -1;
-#pragma unroll
-                for (int k = 0; k < NB; ++k)
-                {
-                    res[k] = 0.0;
-                    fl[k] = 0;
-                }
-                if (f < nf)
-                {
-                    const uint16_t *fli = A.face_lidx + (size_t)(f_begin + f) * NB;
-                    const double *af = A.aF + (size_t)nqF * A.face_id[f_begin + f];
-                    fc = A.face_col[f_begin + f];
-                    double w[NB];
-#pragma unroll
-                    for (int k = 0; k < NB; ++k)
-                    {
-                        fl[k] = fli[k];
-                        w[k] = xo[fl[k]];
-                    }
-                    for (int q = 0; q < nqF; ++q)
-                    {
-                        double pv = 0.0;
-#pragma unroll
-                        for (int k = 0; k < NB; ++k)
-                            pv += PF[q + nqF * k] * w[k];
-                        pv *= af[q];
-#pragma unroll
-                        for (int k = 0; k < NB; ++k)
-                            res[k] += PF[q + nqF * k] * pv;
-                    }
-                }
-                for (int c = 0; c < A.nfcol; ++c)
-                {
-                    if (fc == c)
-                    {
-#pragma unroll
-                        for (int k = 0; k < NB; ++k)
-                            yc[fl[k]] -= A.omega * res[k];
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                }
-            }
-        }
-        __syncthreads();
-
-        // write out the sum of the three copies (fixed order)
-        const int *slot = A.slot_of + off;
-        for (int base = 0; base < nloc; base += 384)
-        {
-            int si[2], gi[2];
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-            {
-                const int i = min(base + 192 * j + tid, nloc - 1);
-                si[j] = slot[i];
-                gi[j] = dofs[i];
-            }
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-            {
-                const int i = base + 192 * j + tid;
-                if (i >= nloc)
-                    continue;
-                const double yu = (lds[2 * ML + i] + lds[4 * ML + i]) + lds[6 * ML + i];
-                const double yv = (lds[3 * ML + i] + lds[5 * ML + i]) + lds[7 * ML + i];
-                if (si[j] < 0)
-                {
-                    A.y[gi[j]] = yu;
-                    A.y[A.ndof + gi[j]] = yv;
-                }
-                else
-                {
-                    A.part[si[j]] = yu;
-                    A.part[A.n_slots + si[j]] = yv;
-                }
-            }
-        }
-    }
-
     __global__ void __launch_bounds__(256) helm_border_kernel(int n_shared, int ndof, int n_slots, const int *__restrict__ shared_dof,
                                                              const int *__restrict__ shared_off, const int *__restrict__ shared_slots,
                                                              const double *__restrict__ part, double *__restrict__ y)
@@ -790,25 +438,14 @@ namespace
     template <int NB, int NQS, int NQM>
     void launch_patch(const cuddh_helmholtz_plan *p, const HelmArgs &A, hipStream_t st)
     {
-        if (p->waves == 3)
-        {
-            const size_t lds3 = (size_t)8 * p->max_loc * sizeof(double);
-            hipLaunchKernelGGL((helm_patch3_kernel<NB, NQS, NQM>), dim3(8 * A.xcd_chunk), dim3(192), lds3, st, A, p->PS, p->DS, p->PM, p->PF);
-            return;
-        }
         const size_t lds = (size_t)4 * p->max_loc * sizeof(double);
-        if (p->prefetch == 1)
-            hipLaunchKernelGGL((helm_patch_kernel<NB, NQS, NQM, 1>), dim3(8 * A.xcd_chunk), dim3(64), lds, st, A, p->PS, p->DS, p->PM, p->PF);
-        else if (p->prefetch == 2)
-            hipLaunchKernelGGL((helm_patch_kernel<NB, NQS, NQM, 2>), dim3(8 * A.xcd_chunk), dim3(64), lds, st, A, p->PS, p->DS, p->PM, p->PF);
-        else
-            hipLaunchKernelGGL((helm_patch_kernel<NB, NQS, NQM, 0>), dim3(8 * A.xcd_chunk), dim3(64), lds, st, A, p->PS, p->DS, p->PM, p->PF);
+        hipLaunchKernelGGL((helm_patch_kernel<NB, NQS, NQM>), dim3(8 * A.xcd_chunk), dim3(64), lds, st, A, p->PS, p->DS, p->PM, p->PF);
     }
 
     bool supported(int nb, int nqS, int nqM)
     {
         return (nb == 3 && nqS == 4 && nqM == 6) || (nb == 4 && nqS == 5 && nqM == 8) || (nb == 5 && nqS == 6 && nqM == 9) ||
-               (nb == 2 && nqS == 3 && nqM == 5);
+               (nb == 2 && nqS == 3 && nqM == 5) || (nb == 6 && nqS == 7 && nqM == 11);
     }
 
     HelmArgs plan_args(const cuddh_helmholtz_plan *p, const double *x, double *y)
@@ -1078,7 +715,7 @@ namespace
     // kind 0: stiffness with nq = nb + 1; kind 1: mass with nq = nb + 1 (a == 1) or 1 + 3 nb / 2 + 1 (weighted)
     bool op_supported(int kind, int nb, int nq)
     {
-        if (nb < 2 || nb > 5)
+        if (nb < 2 || nb > 5) // n_basis 6 measured slower than the generic kernels here (256 VGPRs + spills at 2 waves/SIMD)
             return false;
         if (kind == 0)
             return nq == nb + 1;
@@ -1151,10 +788,6 @@ extern "C"
         p->nqF = nqF;
         p->n_faces = n_faces;
         p->aF = a_F;
-        if (const char *e = std::getenv("CUDDH_HELM_PREFETCH"))
-            p->prefetch = std::atoi(e);
-        if (const char *e = std::getenv("CUDDH_HELM_WAVES"))
-            p->waves = std::atoi(e) == 3 ? 3 : 1;
         const int nn = nb * nb;
 
         // ---- element order: Morton curve over the centroids
@@ -1444,6 +1077,8 @@ extern "C"
             launch_patch<3, 4, 6>(p, A, st);
         else if (p->nb == 5)
             launch_patch<5, 6, 9>(p, A, st);
+        else if (p->nb == 6)
+            launch_patch<6, 7, 11>(p, A, st);
         else
             launch_patch<2, 3, 5>(p, A, st);
         int err = launch_status();

@@ -34,6 +34,16 @@ def timeit(f, reps=20):
     return e0.elapsed_time(e1) * 1e-3 / reps
 
 
+fs = cd.FaceSpace(fem, mesh.boundary_edges())
+A = cd.HelmholtzOperator(math.pi * nx / 32, coef, torch.ones(fs.size(), dtype=torch.float64, device=dev), fem, fs)
+xx = torch.rand(2 * n, dtype=torch.float64, device=dev)
+yy = torch.empty_like(xx)
+if A.fused():
+    t = timeit(lambda: A.action(xx, yy))
+    b = A.bytes_per_apply()
+    print(f"nx={nx} nb={nb} fused complex apply:          {t * 1e6:9.1f} us  {b / t / 1e9:8.1f} GB/s algorithmic ({b / 1e6:.1f} MB)")
+t = timeit(lambda: A.action_unfused(xx, yy))
+print(f"nx={nx} nb={nb} unfused composite:            {t * 1e6:9.1f} us")
 S = cd.StiffnessMatrix(fem)
 M = cd.MassMatrix(fem)
 Mw = cd.MassMatrix(fem, coef)

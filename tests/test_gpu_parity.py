@@ -86,7 +86,7 @@ def test_blas1(cuda, dtype, n):
 
 # ------------------------------------------------------------------ operators vs oracle
 @pytest.mark.parametrize("kind", ["structured", "unstructured"])
-@pytest.mark.parametrize("nb", [2, 3, 4, 5, 8])
+@pytest.mark.parametrize("nb", [2, 3, 4, 5, 6, 8])
 def test_stiffness_mass_apply(cuda, kind, nb):
     import torch
 
@@ -279,7 +279,7 @@ def test_linear_functionals_vs_oracle(cuda):
 
 # ------------------------------------------------------------------ fused Helmholtz apply
 @pytest.mark.parametrize("kind,nx", [("structured", 10), ("structured", 37), ("unstructured", 0)])
-@pytest.mark.parametrize("nb", [2, 3, 4, 5])
+@pytest.mark.parametrize("nb", [2, 3, 4, 5, 6])
 def test_fused_helmholtz_apply(cuda, kind, nx, nb):
     import torch
 
