@@ -20,6 +20,7 @@
 // The apply is therefore bitwise reproducible and needs no zero-fill of y.
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -52,11 +53,24 @@ struct cuddh_helmholtz_plan
     int *shared_dof = nullptr, *shared_off = nullptr, *shared_slots = nullptr;
     double *part = nullptr; // [2][n_slots]
     size_t bytes_alg = 0, bytes_actual = 0;
+    int streaming = 0; // metric loads carry the non-temporal hint (plans larger than the infinity cache)
 };
 
 namespace
 {
     constexpr int PE = 32; // elements per patch
+
+    // metric arrays are read exactly once per apply: when the plan does not fit the 256 MB infinity cache anyway they
+    // are loaded with the streaming hint so that they do not evict x, y and the dof lists (NT); small plans keep the
+    // default policy and stay cache resident from one apply to the next
+    template <bool NT>
+    __device__ inline double metric_load(const double *p)
+    {
+        if constexpr (NT)
+            return __builtin_nontemporal_load(p);
+        else
+            return *p;
+    }
 
     struct HelmArgs
     {
@@ -73,7 +87,7 @@ namespace
 
     // Variants measured and dropped: software-pipelined slice loads, slices split between the half-waves
     // and exchanged with ds_bpermute, three role-specialised wavefronts per patch, touch-prefetch of the metric block.
-    template <int NB, int NQS, int NQM>
+    template <int NB, int NQS, int NQM, bool NT>
     __global__ void __launch_bounds__(64, (NB >= 5 ? 2 : 4)) helm_patch_kernel(HelmArgs A, const double *__restrict__ PS, const double *__restrict__ DS,
                                                            const double *__restrict__ PM, const double *__restrict__ PF)
     {
@@ -156,9 +170,9 @@ namespace
 #pragma unroll
             for (int r = 0; r < NQS; ++r)
             {
-                g[3 * r + 0] = Gp[((q * 3 + 0) * NQS + r) * PE];
-                g[3 * r + 1] = Gp[((q * 3 + 1) * NQS + r) * PE];
-                g[3 * r + 2] = Gp[((q * 3 + 2) * NQS + r) * PE];
+                g[3 * r + 0] = metric_load<NT>(&Gp[((q * 3 + 0) * NQS + r) * PE]);
+                g[3 * r + 1] = metric_load<NT>(&Gp[((q * 3 + 1) * NQS + r) * PE]);
+                g[3 * r + 2] = metric_load<NT>(&Gp[((q * 3 + 2) * NQS + r) * PE]);
             }
         };
         auto stiff_slice = [&](int q, const double (&g)[3 * NQS])
@@ -212,7 +226,7 @@ namespace
         {
 #pragma unroll
             for (int r = 0; r < NQM; ++r)
-                a[r] = ap[(q * NQM + r) * PE];
+                a[r] = metric_load<NT>(&ap[(q * NQM + r) * PE]);
         };
         auto mass_slice = [&](int q, const double (&am)[NQM])
         {
@@ -439,7 +453,10 @@ namespace
     void launch_patch(const cuddh_helmholtz_plan *p, const HelmArgs &A, hipStream_t st)
     {
         const size_t lds = (size_t)4 * p->max_loc * sizeof(double);
-        hipLaunchKernelGGL((helm_patch_kernel<NB, NQS, NQM>), dim3(8 * A.xcd_chunk), dim3(64), lds, st, A, p->PS, p->DS, p->PM, p->PF);
+        if (p->streaming)
+            hipLaunchKernelGGL((helm_patch_kernel<NB, NQS, NQM, true>), dim3(8 * A.xcd_chunk), dim3(64), lds, st, A, p->PS, p->DS, p->PM, p->PF);
+        else
+            hipLaunchKernelGGL((helm_patch_kernel<NB, NQS, NQM, false>), dim3(8 * A.xcd_chunk), dim3(64), lds, st, A, p->PS, p->DS, p->PM, p->PF);
     }
 
     bool supported(int nb, int nqS, int nqM)
@@ -483,7 +500,7 @@ namespace
     // y = [y +] c * S x  (KIND 0)  or  y = [y +] c * M x  (KIND 1) on a real vector.  Same patches, layouts and colour
     // phases as the complex kernel; the two half-waves now work on two DIFFERENT patches (2*pair and 2*pair + 1), so
     // every metric load instruction still fetches 2 x 256 contiguous bytes and no lane idles.
-    template <int NB, int NQ, int KIND>
+    template <int NB, int NQ, int KIND, bool NT>
     __global__ void __launch_bounds__(64, (NB >= 5 ? 2 : 4)) op_patch_kernel(HelmArgs A, int accumulate, const double *__restrict__ P,
                                                                              const double *__restrict__ D)
     {
@@ -558,9 +575,9 @@ namespace
 #pragma unroll
                 for (int r = 0; r < NQ; ++r)
                 {
-                    g[3 * r + 0] = Gp[((q * 3 + 0) * NQ + r) * PE];
-                    g[3 * r + 1] = Gp[((q * 3 + 1) * NQ + r) * PE];
-                    g[3 * r + 2] = Gp[((q * 3 + 2) * NQ + r) * PE];
+                    g[3 * r + 0] = metric_load<NT>(&Gp[((q * 3 + 0) * NQ + r) * PE]);
+                    g[3 * r + 1] = metric_load<NT>(&Gp[((q * 3 + 1) * NQ + r) * PE]);
+                    g[3 * r + 2] = metric_load<NT>(&Gp[((q * 3 + 2) * NQ + r) * PE]);
                 }
                 double pu[NB], du[NB], t0[NB], t1[NB];
 #pragma unroll
@@ -613,7 +630,7 @@ namespace
                 double am[NQ];
 #pragma unroll
                 for (int r = 0; r < NQ; ++r)
-                    am[r] = ap[(q * NQ + r) * PE];
+                    am[r] = metric_load<NT>(&ap[(q * NQ + r) * PE]);
                 double pu[NB], t[NB];
 #pragma unroll
                 for (int l = 0; l < NB; ++l)
@@ -726,8 +743,12 @@ namespace
     void launch_op_one(const cuddh_helmholtz_plan *p, const HelmArgs &A, int accumulate, hipStream_t st)
     {
         const size_t lds = (size_t)4 * p->max_loc * sizeof(double);
-        hipLaunchKernelGGL((op_patch_kernel<NB, NQ, KIND>), dim3(8 * A.xcd_chunk), dim3(64), lds, st, A, accumulate,
-                           KIND == 0 ? p->PS : p->PM, p->DS);
+        if (p->streaming)
+            hipLaunchKernelGGL((op_patch_kernel<NB, NQ, KIND, true>), dim3(8 * A.xcd_chunk), dim3(64), lds, st, A, accumulate,
+                               KIND == 0 ? p->PS : p->PM, p->DS);
+        else
+            hipLaunchKernelGGL((op_patch_kernel<NB, NQ, KIND, false>), dim3(8 * A.xcd_chunk), dim3(64), lds, st, A, accumulate,
+                               KIND == 0 ? p->PS : p->PM, p->DS);
     }
 
     bool launch_op(const cuddh_helmholtz_plan *p, const HelmArgs &A, int accumulate, hipStream_t st)
@@ -1011,6 +1032,9 @@ extern "C"
         p->bytes_actual = (size_t)nG * 8 + (size_t)nA * 8 + lidx.size() * 4 + colour.size() + dof_list.size() * (4 + 4 + 16) +
                           exclusive * 16 + (size_t)n_slots * (16 + 16 + 4) + (size_t)n_shared * (16 + 8) +
                           (size_t)n_faces * ((size_t)nqF * 8 + (size_t)nb * 2 + 5);
+        p->streaming = p->bytes_actual > (size_t)256 << 20; // the infinity cache
+        if (const char *e = std::getenv("CUDDH_PLAN_STREAMING")) // measurement knob: 0 / 1 overrides the size rule
+            p->streaming = std::atoi(e) != 0;
         *out = p;
         return 0;
     }
