@@ -299,6 +299,10 @@ class HelmholtzOperator(_Operator):
     def bytes_per_apply(self, actual: bool = False) -> int:
         return int(lib.cuddh_helmholtz_bytes(self._h, 1 if actual else 0))
 
+    def bytes_affine(self) -> int:
+        """SURVEY 8d's "affine" figure when the plan reads the stiffness metric from one uniform table (0 otherwise)"""
+        return int(lib.cuddh_helmholtz_bytes(self._h, 2))
+
 
 # integrand ids of cuddh_capi.h
 GAUSSIANS, ALPHA_DISK, MASS_POLY, STIFF_NEG_LAPLACIAN, STIFF_FUNC, CONSTANT, ALPHA_DISK_SQ = range(7)

@@ -38,6 +38,9 @@ namespace cuddh
 
         /// bytes per apply: algorithmic (SURVEY 8d formula) or as laid out by the plan
         std::size_t bytes_per_apply(bool actual) const;
+        /// bytes of the "affine" form when the plan found the stiffness metric identical in every element
+        /// (uniform meshes: it is then read from one small table instead of n_elem copies); 0 otherwise
+        std::size_t bytes_affine() const;
 
     private:
         const double omega;

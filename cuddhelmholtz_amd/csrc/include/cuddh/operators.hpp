@@ -33,6 +33,7 @@ namespace cuddh
             const cuddh_helmholtz_plan *get(int kind, const H1Space &fem, int n_quad, const double *h_P, const double *h_D,
                                             const double *d_metric) const;
             std::size_t bytes(bool actual) const;
+            std::size_t bytes_affine() const;
 
         private:
             mutable cuddh_helmholtz_plan *plan = nullptr;

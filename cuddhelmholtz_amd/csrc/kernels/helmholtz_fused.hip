@@ -19,6 +19,7 @@
 //     to per-patch slots that a second small kernel sums in a fixed order.
 // The apply is therefore bitwise reproducible and needs no zero-fill of y.
 #include <algorithm>
+#include <cmath>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
@@ -41,6 +42,9 @@ struct cuddh_helmholtz_plan
     uint8_t *colour = nullptr; // [n_patches][32]
     double *Gp = nullptr;     // [n_patches][q: nqS][3][r: nqS][32]  (point (q,r) = xi index q, eta index r)
     double *aMp = nullptr;    // [n_patches][q: nqM][r: nqM][32]
+    // affine meshes (every element has the same metric array, e.g. uniform_rect): one copy, read through scalar loads
+    double *Gu = nullptr; // [q][3][r]  (then Gp is not allocated)
+    double *au = nullptr; // [q][r]     (then aMp is not allocated)
     // faces, grouped by patch
     int *face_off = nullptr;       // [n_patches + 1]
     uint16_t *face_lidx = nullptr; // [n_faces_total][nb]
@@ -54,6 +58,7 @@ struct cuddh_helmholtz_plan
     double *part = nullptr; // [2][n_slots]
     size_t bytes_alg = 0, bytes_actual = 0;
     int streaming = 0; // metric loads carry the non-temporal hint (plans larger than the infinity cache)
+    size_t bytes_affine = 0; // algorithmic bytes of the affine form (0 when neither metric array is uniform)
 };
 
 namespace
@@ -87,9 +92,11 @@ namespace
 
     // Variants measured and dropped: software-pipelined slice loads, slices split between the half-waves
     // and exchanged with ds_bpermute, three role-specialised wavefronts per patch, touch-prefetch of the metric block.
-    template <int NB, int NQS, int NQM, bool NT>
+    // UG: the stiffness metric is the same in every element and comes from the uniform table GU (scalar loads)
+    template <int NB, int NQS, int NQM, bool NT, bool UG>
     __global__ void __launch_bounds__(64, (NB >= 5 ? 2 : 4)) helm_patch_kernel(HelmArgs A, const double *__restrict__ PS, const double *__restrict__ DS,
-                                                           const double *__restrict__ PM, const double *__restrict__ PF)
+                                                           const double *__restrict__ PM, const double *__restrict__ PF,
+                                                           const double *__restrict__ GU)
     {
         constexpr int NN = NB * NB;
         extern __shared__ double lds[];
@@ -170,9 +177,18 @@ namespace
 #pragma unroll
             for (int r = 0; r < NQS; ++r)
             {
-                g[3 * r + 0] = metric_load<NT>(&Gp[((q * 3 + 0) * NQS + r) * PE]);
-                g[3 * r + 1] = metric_load<NT>(&Gp[((q * 3 + 1) * NQS + r) * PE]);
-                g[3 * r + 2] = metric_load<NT>(&Gp[((q * 3 + 2) * NQS + r) * PE]);
+                if constexpr (UG)
+                {
+                    g[3 * r + 0] = GU[(q * 3 + 0) * NQS + r];
+                    g[3 * r + 1] = GU[(q * 3 + 1) * NQS + r];
+                    g[3 * r + 2] = GU[(q * 3 + 2) * NQS + r];
+                }
+                else
+                {
+                    g[3 * r + 0] = metric_load<NT>(&Gp[((q * 3 + 0) * NQS + r) * PE]);
+                    g[3 * r + 1] = metric_load<NT>(&Gp[((q * 3 + 1) * NQS + r) * PE]);
+                    g[3 * r + 2] = metric_load<NT>(&Gp[((q * 3 + 2) * NQS + r) * PE]);
+                }
             }
         };
         auto stiff_slice = [&](int q, const double (&g)[3 * NQS])
@@ -402,6 +418,65 @@ namespace
         }
     }
 
+    template <typename T>
+    int upload(T **dst, const std::vector<T> &v)
+    {
+        *dst = nullptr;
+        if (v.empty())
+            return 0;
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(dst), v.size() * sizeof(T));
+        if (e != hipSuccess)
+            return static_cast<int>(e);
+        return static_cast<int>(hipMemcpy(*dst, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    }
+
+    // does every element's block of `per_elem` values equal element 0's, to the absolute tolerance tol?
+    __global__ void __launch_bounds__(256) uniform_metric_kernel(long long total, int per_elem, const double *__restrict__ src, double tol,
+                                                                int *__restrict__ differs)
+    {
+        for (long long t = blockIdx.x * 256LL + threadIdx.x; t < total; t += gridDim.x * 256LL)
+            if (fabs(src[t] - src[t % per_elem]) > tol)
+                atomicExch(differs, 1);
+    }
+
+    // If the reference-layout metric array (comps, nq, nq, n_elem) is the same for every element (to 1e-13 of its largest
+    // entry), upload one copy as [q][c][r] and return it in *table; otherwise leave *table null.
+    int uniform_table(double **table, int comps, int nq, int n_elem, const double *d_src)
+    {
+        *table = nullptr;
+        const int per_elem = comps * nq * nq;
+        std::vector<double> block(per_elem);
+        hipError_t e = hipMemcpy(block.data(), d_src, per_elem * sizeof(double), hipMemcpyDeviceToHost);
+        if (e != hipSuccess)
+            return static_cast<int>(e);
+        double scale = 0.0;
+        for (double v : block)
+            scale = std::max(scale, std::fabs(v));
+        int *flag = nullptr, differs = 1;
+        e = hipMalloc(reinterpret_cast<void **>(&flag), sizeof(int));
+        if (e == hipSuccess)
+            e = hipMemset(flag, 0, sizeof(int));
+        if (e == hipSuccess)
+        {
+            const long long total = (long long)per_elem * n_elem;
+            hipLaunchKernelGGL(uniform_metric_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, nullptr, total, per_elem, d_src,
+                               1e-13 * scale, flag);
+            e = hipMemcpy(&differs, flag, sizeof(int), hipMemcpyDeviceToHost);
+        }
+        if (flag)
+            (void)hipFree(flag);
+        if (e != hipSuccess)
+            return static_cast<int>(e);
+        if (differs)
+            return 0;
+        std::vector<double> t(per_elem);
+        for (int q = 0; q < nq; ++q)
+            for (int c = 0; c < comps; ++c)
+                for (int r = 0; r < nq; ++r)
+                    t[(q * comps + c) * nq + r] = block[c + comps * (q + nq * r)];
+        return upload(table, t);
+    }
+
     // reference layout (c, q, r, el) -> [patch][q][c][r][32]
     __global__ void __launch_bounds__(256) repack_kernel(long long total, int comps, int nq, const int *__restrict__ perm,
                                                         const double *__restrict__ src, double *__restrict__ dst)
@@ -419,18 +494,6 @@ namespace
             const int el = perm[patch * PE + le];
             dst[t] = el >= 0 ? src[c + (size_t)comps * ((q + (size_t)nq * r) + (size_t)nq * nq * el)] : 0.0;
         }
-    }
-
-    template <typename T>
-    int upload(T **dst, const std::vector<T> &v)
-    {
-        *dst = nullptr;
-        if (v.empty())
-            return 0;
-        hipError_t e = hipMalloc(reinterpret_cast<void **>(dst), v.size() * sizeof(T));
-        if (e != hipSuccess)
-            return static_cast<int>(e);
-        return static_cast<int>(hipMemcpy(*dst, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
     }
 
     int upload_raw(double **dst, const double *src, size_t n)
@@ -453,10 +516,15 @@ namespace
     void launch_patch(const cuddh_helmholtz_plan *p, const HelmArgs &A, hipStream_t st)
     {
         const size_t lds = (size_t)4 * p->max_loc * sizeof(double);
-        if (p->streaming)
-            hipLaunchKernelGGL((helm_patch_kernel<NB, NQS, NQM, true>), dim3(8 * A.xcd_chunk), dim3(64), lds, st, A, p->PS, p->DS, p->PM, p->PF);
+        const dim3 grid(8 * A.xcd_chunk), block(64);
+        if (p->Gu && p->streaming)
+            hipLaunchKernelGGL((helm_patch_kernel<NB, NQS, NQM, true, true>), grid, block, lds, st, A, p->PS, p->DS, p->PM, p->PF, p->Gu);
+        else if (p->Gu)
+            hipLaunchKernelGGL((helm_patch_kernel<NB, NQS, NQM, false, true>), grid, block, lds, st, A, p->PS, p->DS, p->PM, p->PF, p->Gu);
+        else if (p->streaming)
+            hipLaunchKernelGGL((helm_patch_kernel<NB, NQS, NQM, true, false>), grid, block, lds, st, A, p->PS, p->DS, p->PM, p->PF, p->Gu);
         else
-            hipLaunchKernelGGL((helm_patch_kernel<NB, NQS, NQM, false>), dim3(8 * A.xcd_chunk), dim3(64), lds, st, A, p->PS, p->DS, p->PM, p->PF);
+            hipLaunchKernelGGL((helm_patch_kernel<NB, NQS, NQM, false, false>), grid, block, lds, st, A, p->PS, p->DS, p->PM, p->PF, p->Gu);
     }
 
     bool supported(int nb, int nqS, int nqM)
@@ -500,9 +568,10 @@ namespace
     // y = [y +] c * S x  (KIND 0)  or  y = [y +] c * M x  (KIND 1) on a real vector.  Same patches, layouts and colour
     // phases as the complex kernel; the two half-waves now work on two DIFFERENT patches (2*pair and 2*pair + 1), so
     // every metric load instruction still fetches 2 x 256 contiguous bytes and no lane idles.
-    template <int NB, int NQ, int KIND, bool NT>
+    // UM: the metric array of this operator is the same in every element and comes from the uniform table MU
+    template <int NB, int NQ, int KIND, bool NT, bool UM>
     __global__ void __launch_bounds__(64, (NB >= 5 ? 2 : 4)) op_patch_kernel(HelmArgs A, int accumulate, const double *__restrict__ P,
-                                                                             const double *__restrict__ D)
+                                                                             const double *__restrict__ D, const double *__restrict__ MU)
     {
         constexpr int NN = NB * NB, NP = (NN + 1) / 2;
         extern __shared__ double lds[];
@@ -575,9 +644,18 @@ namespace
 #pragma unroll
                 for (int r = 0; r < NQ; ++r)
                 {
-                    g[3 * r + 0] = metric_load<NT>(&Gp[((q * 3 + 0) * NQ + r) * PE]);
-                    g[3 * r + 1] = metric_load<NT>(&Gp[((q * 3 + 1) * NQ + r) * PE]);
-                    g[3 * r + 2] = metric_load<NT>(&Gp[((q * 3 + 2) * NQ + r) * PE]);
+                    if constexpr (UM)
+                    {
+                        g[3 * r + 0] = MU[(q * 3 + 0) * NQ + r];
+                        g[3 * r + 1] = MU[(q * 3 + 1) * NQ + r];
+                        g[3 * r + 2] = MU[(q * 3 + 2) * NQ + r];
+                    }
+                    else
+                    {
+                        g[3 * r + 0] = metric_load<NT>(&Gp[((q * 3 + 0) * NQ + r) * PE]);
+                        g[3 * r + 1] = metric_load<NT>(&Gp[((q * 3 + 1) * NQ + r) * PE]);
+                        g[3 * r + 2] = metric_load<NT>(&Gp[((q * 3 + 2) * NQ + r) * PE]);
+                    }
                 }
                 double pu[NB], du[NB], t0[NB], t1[NB];
 #pragma unroll
@@ -630,7 +708,7 @@ namespace
                 double am[NQ];
 #pragma unroll
                 for (int r = 0; r < NQ; ++r)
-                    am[r] = metric_load<NT>(&ap[(q * NQ + r) * PE]);
+                    am[r] = UM ? MU[q * NQ + r] : metric_load<NT>(&ap[(q * NQ + r) * PE]);
                 double pu[NB], t[NB];
 #pragma unroll
                 for (int l = 0; l < NB; ++l)
@@ -743,12 +821,14 @@ namespace
     void launch_op_one(const cuddh_helmholtz_plan *p, const HelmArgs &A, int accumulate, hipStream_t st)
     {
         const size_t lds = (size_t)4 * p->max_loc * sizeof(double);
-        if (p->streaming)
-            hipLaunchKernelGGL((op_patch_kernel<NB, NQ, KIND, true>), dim3(8 * A.xcd_chunk), dim3(64), lds, st, A, accumulate,
-                               KIND == 0 ? p->PS : p->PM, p->DS);
+        const dim3 grid(8 * A.xcd_chunk), block(64);
+        const double *P = KIND == 0 ? p->PS : p->PM, *MU = KIND == 0 ? p->Gu : p->au;
+        if (MU)
+            hipLaunchKernelGGL((op_patch_kernel<NB, NQ, KIND, false, true>), grid, block, lds, st, A, accumulate, P, p->DS, MU);
+        else if (p->streaming)
+            hipLaunchKernelGGL((op_patch_kernel<NB, NQ, KIND, true, false>), grid, block, lds, st, A, accumulate, P, p->DS, MU);
         else
-            hipLaunchKernelGGL((op_patch_kernel<NB, NQ, KIND, false>), dim3(8 * A.xcd_chunk), dim3(64), lds, st, A, accumulate,
-                               KIND == 0 ? p->PS : p->PM, p->DS);
+            hipLaunchKernelGGL((op_patch_kernel<NB, NQ, KIND, false, false>), grid, block, lds, st, A, accumulate, P, p->DS, MU);
     }
 
     bool launch_op(const cuddh_helmholtz_plan *p, const HelmArgs &A, int accumulate, hipStream_t st)
@@ -783,7 +863,7 @@ extern "C"
     {
         if (!p)
             return 0;
-        void *ptrs[] = {p->dof_off, p->dof_list, p->slot_of, p->patch_nel, p->lidx, p->colour, p->Gp, p->aMp, p->face_off,
+        void *ptrs[] = {p->dof_off, p->dof_list, p->slot_of, p->patch_nel, p->lidx, p->colour, p->Gp, p->aMp, p->Gu, p->au, p->face_off,
                         p->face_lidx, p->face_id, p->face_col, p->PS, p->DS, p->PM, p->PF, p->shared_dof, p->shared_off,
                         p->shared_slots, p->part};
         for (void *q : ptrs)
@@ -1001,7 +1081,16 @@ extern "C"
 
         int *d_perm = nullptr;
         ok(upload(&d_perm, padded_perm));
-        const long long nG = (long long)n_patches * 3 * nqS * nqS * PE, nA = (long long)n_patches * nqM * nqM * PE;
+        // affine meshes: one copy of a metric array instead of one per element (CUDDH_PLAN_AFFINE=0 keeps the general form)
+        bool try_affine = true;
+        if (const char *e = std::getenv("CUDDH_PLAN_AFFINE"))
+            try_affine = std::atoi(e) != 0;
+        if (try_affine && nqS > 0)
+            ok(uniform_table(&p->Gu, 3, nqS, n_elem, G_S));
+        if (try_affine && nqM > 0 && nqS == 0) // the fused complex kernel always reads per-element mass weights (they carry a(x)^2)
+            ok(uniform_table(&p->au, 1, nqM, n_elem, a_M));
+        const long long nG = p->Gu ? 0 : (long long)n_patches * 3 * nqS * nqS * PE;
+        const long long nA = p->au ? 0 : (long long)n_patches * nqM * nqM * PE;
         if (nG > 0)
             ok(static_cast<int>(hipMalloc(reinterpret_cast<void **>(&p->Gp), nG * sizeof(double))));
         if (nA > 0)
@@ -1032,6 +1121,8 @@ extern "C"
         p->bytes_actual = (size_t)nG * 8 + (size_t)nA * 8 + lidx.size() * 4 + colour.size() + dof_list.size() * (4 + 4 + 16) +
                           exclusive * 16 + (size_t)n_slots * (16 + 16 + 4) + (size_t)n_shared * (16 + 8) +
                           (size_t)n_faces * ((size_t)nqF * 8 + (size_t)nb * 2 + 5);
+        if (p->Gu || p->au) // SURVEY 8d's "affine" figure: the uniform metric arrays are not traffic
+            p->bytes_affine = p->bytes_alg - (size_t)n_elem * ((p->Gu ? (size_t)3 * nqS * nqS * 8 : 0) + (p->au ? (size_t)nqM * nqM * 8 : 0));
         p->streaming = p->bytes_actual > (size_t)256 << 20; // the infinity cache
         if (const char *e = std::getenv("CUDDH_PLAN_STREAMING")) // measurement knob: 0 / 1 overrides the size rule
             p->streaming = std::atoi(e) != 0;
@@ -1119,6 +1210,8 @@ extern "C"
 
     size_t cuddh_hip_helmholtz_plan_bytes(const cuddh_helmholtz_plan *p, int actual)
     {
-        return p ? (actual ? p->bytes_actual : p->bytes_alg) : 0;
+        if (!p)
+            return 0;
+        return actual == 2 ? p->bytes_affine : (actual ? p->bytes_actual : p->bytes_alg);
     }
 }

@@ -442,7 +442,9 @@ extern "C"
     size_t cuddh_helmholtz_bytes(void *op, int actual)
     {
         auto *h = static_cast<OpHandle *>(op);
-        return h->helm ? h->helm->bytes_per_apply(actual != 0) : 0;
+        if (!h->helm)
+            return 0;
+        return actual == 2 ? h->helm->bytes_affine() : h->helm->bytes_per_apply(actual != 0);
     }
 
     // ------------------------------------------------------------ functionals

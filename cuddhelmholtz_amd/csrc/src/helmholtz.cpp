@@ -89,6 +89,8 @@ namespace cuddh
         scal(ndof, -1.0, Av);
     }
 
+    std::size_t HelmholtzOperator::bytes_affine() const { return cuddh_hip_helmholtz_plan_bytes(plan, 2); }
+
     std::size_t HelmholtzOperator::bytes_per_apply(bool actual) const
     {
         return cuddh_hip_helmholtz_plan_bytes(plan, actual ? 1 : 0);

@@ -42,6 +42,7 @@ namespace cuddh
         }
 
         std::size_t OperatorPlan::bytes(bool actual) const { return cuddh_hip_helmholtz_plan_bytes(plan, actual ? 1 : 0); }
+        std::size_t OperatorPlan::bytes_affine() const { return cuddh_hip_helmholtz_plan_bytes(plan, 2); }
     } // namespace detail
 
     namespace

@@ -81,7 +81,7 @@ int cuddh_operator_apply(void *op, const double *x, double *y);               /*
 int cuddh_operator_apply_add(void *op, double c, const double *x, double *y); /* y += c A x */
 int cuddh_helmholtz_apply_unfused(void *op, const double *x, double *y);
 int cuddh_helmholtz_is_fused(void *op);
-size_t cuddh_helmholtz_bytes(void *op, int actual);
+size_t cuddh_helmholtz_bytes(void *op, int actual); /* actual: 0 / 1 / 2 as cuddh_hip_helmholtz_plan_bytes */
 
 /* ---- load vectors with built-in integrands (device lambdas cannot cross a C ABI).
  * integrand: 0 two Gaussians of examples/DDH.cpp:61-72 (param = omega)

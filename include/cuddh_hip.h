@@ -148,7 +148,10 @@ int cuddh_hip_helmholtz_plan_create(cuddh_helmholtz_plan **plan, int ndof, int n
 int cuddh_hip_helmholtz_plan_destroy(cuddh_helmholtz_plan *plan);
 /* y = [ S u - w^2 M u - w H v ;  -(S v - w^2 M v + w H u) ],  x = [u;v], y = [Au;Av], each of length ndof */
 int cuddh_hip_helmholtz_apply(const cuddh_helmholtz_plan *plan, double omega, const double *x, double *y, void *stream);
-/* bytes the plan's apply reads+writes per call, by the SURVEY 8d formula and as actually laid out */
+/* bytes the plan's apply reads+writes per call: actual == 0 the SURVEY 8d formula of the general-geometry layout,
+ * 1 as actually laid out, 2 the "affine" figure when the plan found a metric array identical in every element (uniform
+ * meshes: one copy read through scalar loads instead of one per element; 0 otherwise).  CUDDH_PLAN_AFFINE=0 in the
+ * environment at plan creation keeps the general form (used to measure the general-geometry roofline on a uniform mesh). */
 size_t cuddh_hip_helmholtz_plan_bytes(const cuddh_helmholtz_plan *plan, int actual);
 
 /* The same plan machinery for ONE real operator -- the bandwidth path of StiffnessMatrix::action

@@ -277,6 +277,53 @@ def test_linear_functionals_vs_oracle(cuda):
     assert rel(F.cpu().numpy(), oracle.linear_functional(d, oracle.gaussians(omega), nq=7)) < 1e-12
 
 
+# ------------------------------------------------------------------ affine meshes
+@pytest.mark.parametrize("nb", [2, 3, 4, 5])
+def test_affine_and_general_plans_agree(cuda, nb, monkeypatch):
+    """On a uniform mesh every element has the same stiffness metric (and the same unweighted mass weights): the plans
+    then read ONE copy through scalar loads.  CUDDH_PLAN_AFFINE=0 keeps the general per-element arrays; both forms must
+    match the oracle, and each other to rounding."""
+    import torch
+
+    import cuddhelmholtz_amd as cd
+
+    nx = 11
+    pm, om = meshes("structured", nx)
+    d = oracle.Discretization(om, nb)
+    rng = np.random.default_rng(40 + nb)
+    xh = rng.standard_normal(2 * d.ndof)
+    a2 = 0.5 + rng.random(d.ndof)
+    faces = pm.boundary_edges()
+    ofs = oracle.FaceSpaceO(d, list(faces))
+    ax = 0.5 + rng.random(ofs.size)
+    omega = 7.0
+    refS = oracle.Stiffness(d).apply(xh[: d.ndof])
+    refM = oracle.Mass(d).apply(xh[: d.ndof])
+    refA = oracle.helmholtz_apply(d, oracle.Stiffness(d), oracle.Mass(d, a2), oracle.FaceMass(ofs, ax), ofs, omega, xh)
+    got = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("CUDDH_PLAN_AFFINE", mode)
+        fem = cd.H1Space(pm, cd.Basis(nb))
+        fs = cd.FaceSpace(fem, faces)
+        x = to_dev(torch, xh, cuda)
+        yS = torch.full((d.ndof,), 3.0, dtype=torch.float64, device=cuda)
+        yM = torch.full((d.ndof,), 3.0, dtype=torch.float64, device=cuda)
+        cd.StiffnessMatrix(fem).action(x[: d.ndof], yS)
+        cd.MassMatrix(fem).action(x[: d.ndof], yM)
+        A = cd.HelmholtzOperator(omega, to_dev(torch, a2, cuda), to_dev(torch, ax, cuda), fem, fs)
+        y = torch.empty(2 * d.ndof, dtype=torch.float64, device=cuda)
+        A.action(x, y)
+        assert A.fused() and (A.bytes_affine() > 0) == (mode == "1")
+        if mode == "1":  # only the stiffness metric is uniform here (the mass carries the random coefficient a2)
+            n_elem = nx * nx
+            assert A.bytes_per_apply() - A.bytes_affine() == n_elem * 3 * (nb + 1) ** 2 * 8
+        assert rel(yS.cpu().numpy(), refS) < 1e-12 and rel(yM.cpu().numpy(), refM) < 1e-12
+        assert rel(y.cpu().numpy(), refA) < 1e-12
+        got[mode] = (yS.cpu().numpy(), yM.cpu().numpy(), y.cpu().numpy())
+    for a, b in zip(got["1"], got["0"]):
+        assert rel(a, b) < 1e-13
+
+
 # ------------------------------------------------------------------ fused Helmholtz apply
 @pytest.mark.parametrize("kind,nx", [("structured", 10), ("structured", 37), ("unstructured", 0)])
 @pytest.mark.parametrize("nb", [2, 3, 4, 5, 6])
