@@ -296,21 +296,41 @@ def helmholtz_roofline(cd, torch, dev, fem, mesh, omega, ndof):
     fs = cd.FaceSpace(fem, faces)
     a2 = torch.ones(ndof, dtype=torch.float64, device=dev)
     ax = torch.ones(fs.size(), dtype=torch.float64, device=dev)
-    A = cd.HelmholtzOperator(omega, a2, ax, fem, fs)
     g = torch.Generator(device="cpu").manual_seed(12345)
     x = (2.0 * torch.rand(2 * ndof, generator=g, dtype=torch.float64) - 1.0).to(dev)
     y = torch.empty_like(x)
-    for _ in range(5):
-        A.action(x, y)
-    torch.cuda.synchronize()
-    reps = 30
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        A.action(x, y)
-    e1.record()
-    torch.cuda.synchronize()
-    t = e0.elapsed_time(e1) * 1e-3 / reps
+
+    def timed(A, reps=30):
+        for _ in range(5):
+            A.action(x, y)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            A.action(x, y)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e-3 / reps
+
+    # the roofline figure is stated on the GENERAL-geometry layout: the plan is told not to exploit that a
+    # uniform_rect mesh has one metric tensor for all elements; the affine form is timed separately and labelled
+    prev = os.environ.get("CUDDH_PLAN_AFFINE")
+    os.environ["CUDDH_PLAN_AFFINE"] = "0"
+    A = cd.HelmholtzOperator(omega, a2, ax, fem, fs)
+    t = timed(A)
+    os.environ["CUDDH_PLAN_AFFINE"] = "1"
+    A_aff = cd.HelmholtzOperator(omega, a2, ax, fem, fs)
+    affine = None
+    if A_aff.fused() and A_aff.bytes_affine() > 0:
+        t_aff = timed(A_aff)
+        affine = {"label": "affine form (uniform mesh: one copy of the stiffness metric, scalar loads) -- NOT the roofline figure",
+                  "seconds_per_apply": t_aff, "affine_bytes": A_aff.bytes_affine(),
+                  "achieved_affine_bytes": A_aff.bytes_affine() / t_aff / 1e9, "unit": "GB/s",
+                  "frac_of_peak_affine_bytes": A_aff.bytes_affine() / t_aff / 1e9 / HBM_PEAK_GBS}
+    if prev is None:
+        del os.environ["CUDDH_PLAN_AFFINE"]
+    else:
+        os.environ["CUDDH_PLAN_AFFINE"] = prev
     b_alg = A.bytes_per_apply(False)
     gbs = b_alg / t / 1e9
     # HBM traffic per apply from the PMC counters (collected in separate rocprofv3 --pmc passes and committed under
@@ -334,6 +354,7 @@ def helmholtz_roofline(cd, torch, dev, fem, mesh, omega, ndof):
         "layout_bytes": A.bytes_per_apply(True),
         "seconds_per_apply": t,
         "complex_dof_per_s": ndof / t,
+        "affine": affine,
     }
 
 

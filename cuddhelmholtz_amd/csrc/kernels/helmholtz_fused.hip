@@ -118,23 +118,48 @@ namespace
         const double *Gp = A.Gp + (size_t)patch * 3 * NQS * NQS * PE + le;
         const double *ap = A.aMp + (size_t)patch * NQM * NQM * PE + le;
 
-        // gather x of the patch's dofs into LDS: indices first, then values, four 64-lane rows at a time, so that
-        // each wave has 4 + 8 loads in flight instead of a chain of dependent single loads
-        for (int base = 0; base < nloc; base += 256)
+        // A wavefront's life is a chain of dependent memory round trips (about 2 us each under load); everything that does
+        // not depend on the LDS copy of x is therefore requested up front: the element -> local-dof map, the colours, the
+        // first metric slice, and the dof indices of the whole patch (384 per pass) before any x value.
+        const bool active = le < A.patch_nel[patch];
+        constexpr int NP = (NN + 1) / 2;
+        const uint32_t *li = A.lidx + ((size_t)patch * NP) * PE + le;
+        // element node -> patch-local dof, two 16-bit indices per register, kept for the gather here and the
+        // scatter below (lidx is padded to 32 lanes per patch, so inactive lanes read valid zeros)
+        uint32_t lpk[NP];
+#pragma unroll
+        for (int j = 0; j < NP; ++j)
+            lpk[j] = li[j * PE];
+        const int mycol = active ? A.colour[patch * PE + le] : -1;
+        constexpr bool PRE = !UG && NB <= 3; // from n_basis 4 on, holding the slice across the gather costs spills
+        double g_first[3 * NQS];
+        if constexpr (PRE)
         {
-            int gi[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int r = 0; r < NQS; ++r)
+            {
+                g_first[3 * r + 0] = metric_load<NT>(&Gp[((0 * 3 + 0) * NQS + r) * PE]);
+                g_first[3 * r + 1] = metric_load<NT>(&Gp[((0 * 3 + 1) * NQS + r) * PE]);
+                g_first[3 * r + 2] = metric_load<NT>(&Gp[((0 * 3 + 2) * NQS + r) * PE]);
+            }
+        }
+
+        constexpr int ROWS = 6; // 64-lane rows per pass: 384 dofs cover a 4x8-element patch of n_basis 4 (325) in one pass
+        for (int base = 0; base < nloc; base += 64 * ROWS)
+        {
+            int gi[ROWS];
+#pragma unroll
+            for (int j = 0; j < ROWS; ++j)
                 gi[j] = dofs[min(base + 64 * j + lane, nloc - 1)];
-            double xu[4], xv[4];
+            double xu[ROWS], xv[ROWS];
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < ROWS; ++j)
             {
                 xu[j] = A.x[gi[j]];
                 xv[j] = A.x[A.ndof + gi[j]];
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < ROWS; ++j)
             {
                 const int i = base + 64 * j + lane;
                 if (i < nloc)
@@ -149,17 +174,7 @@ namespace
         __syncthreads();
 
         // ------------------------------------------------------------ element phase
-        const bool active = le < A.patch_nel[patch];
-        constexpr int NP = (NN + 1) / 2;
-        const uint32_t *li = A.lidx + ((size_t)patch * NP) * PE + le;
         const double *xc = xs + comp * ML;
-
-        // element node -> patch-local dof, two 16-bit indices per register, kept for the gather here and the
-        // scatter below (lidx is padded to 32 lanes per patch, so inactive lanes read valid zeros)
-        uint32_t lpk[NP];
-#pragma unroll
-        for (int j = 0; j < NP; ++j)
-            lpk[j] = li[j * PE];
         auto lix_of = [&](int n) -> int { return (n & 1) ? static_cast<int>(lpk[n >> 1] >> 16) : static_cast<int>(lpk[n >> 1] & 0xFFFFu); };
         const double keep = active ? 1.0 : 0.0;
         double u[NN], out[NN];
@@ -278,8 +293,10 @@ namespace
 
         {
             // q stays a real loop: unrolling it lets the scheduler hoist every load of the element and exhausts the VGPRs
+            if constexpr (PRE)
+                stiff_slice(0, g_first);
 #pragma unroll 1
-            for (int q = 0; q < NQS; ++q)
+            for (int q = PRE ? 1 : 0; q < NQS; ++q)
             {
                 double g[3 * NQS];
                 load_stiff(q, g);
@@ -298,7 +315,6 @@ namespace
         {
             const double sgn = comp ? -1.0 : 1.0; // the v row is negated (symmetrised system)
             double *yc = ys + comp * ML;
-            const int mycol = active ? A.colour[patch * PE + le] : -1;
             for (int c = 0; c < A.ncol; ++c)
             {
                 if (mycol == c)
@@ -369,18 +385,18 @@ namespace
 
         // ------------------------------------------------------------ write out
         const int *slot = A.slot_of + off;
-        for (int base = 0; base < nloc; base += 256)
+        for (int base = 0; base < nloc; base += 64 * ROWS)
         {
-            int si[4], gi[4];
+            int si[ROWS], gi[ROWS];
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < ROWS; ++j)
             {
                 const int i = min(base + 64 * j + lane, nloc - 1);
                 si[j] = slot[i];
                 gi[j] = dofs[i];
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < ROWS; ++j)
             {
                 const int i = base + 64 * j + lane;
                 if (i >= nloc)
@@ -574,6 +590,7 @@ namespace
                                                                              const double *__restrict__ D, const double *__restrict__ MU)
     {
         constexpr int NN = NB * NB, NP = (NN + 1) / 2;
+        constexpr int NM = (KIND == 0 ? 3 : 1) * NQ; // metric values of one slice
         extern __shared__ double lds[];
         const int pair = (blockIdx.x & 7) * A.xcd_chunk + (blockIdx.x >> 3);
         if (2 * pair >= A.n_patches)
@@ -585,45 +602,60 @@ namespace
         double *ys = lds + 2 * ML; // [2 patches][ML]
         const int n_here = min(2, A.n_patches - 2 * pair);
 
-        for (int h = 0; h < n_here; ++h)
+        // the dof lists of the two patches are adjacent: one combined list, split at n0
+        const int off = A.dof_off[2 * pair];
+        const int n0 = A.dof_off[2 * pair + 1] - off;
+        const int ntot = A.dof_off[2 * pair + n_here] - off;
+        const int *dofs = A.dof_list + off;
+
+        // requests that do not depend on the LDS copy of x go out first (see helm_patch_kernel)
+        const bool have = half < n_here;
+        const int patch = have ? 2 * pair + half : 2 * pair; // a missing second patch re-reads the first (results dropped)
+        const bool active = have && le < A.patch_nel[patch];
+        const uint32_t *li = A.lidx + ((size_t)patch * NP) * PE + le;
+        uint32_t lpk[NP];
+#pragma unroll
+        for (int j = 0; j < NP; ++j)
+            lpk[j] = li[j * PE];
+        const int mycol = active ? A.colour[patch * PE + le] : -1;
+        const double *Mp = (KIND == 0 ? A.Gp + (size_t)patch * 3 * NQ * NQ * PE : A.aMp + (size_t)patch * NQ * NQ * PE) + le;
+        auto load_slice = [&](int q, double (&g)[NM])
         {
-            const int off = A.dof_off[2 * pair + h];
-            const int nloc = A.dof_off[2 * pair + h + 1] - off;
-            const int *dofs = A.dof_list + off;
-            for (int base = 0; base < nloc; base += 256)
+#pragma unroll
+            for (int t = 0; t < NM; ++t) // KIND 0: t = c * NQ + r (component c of point (q, r)); KIND 1: t = r
+                g[t] = UM ? MU[q * NM + t] : metric_load<NT>(&Mp[(q * NM + t) * PE]);
+        };
+        double g_first[NM];
+        if constexpr (!UM)
+            load_slice(0, g_first);
+
+        constexpr int ROWS = 12; // 768 dofs per pass: both patches of n_basis 4 (2 x 325) in one
+        for (int base = 0; base < ntot; base += 64 * ROWS)
+        {
+            int gi[ROWS];
+#pragma unroll
+            for (int j = 0; j < ROWS; ++j)
+                gi[j] = dofs[min(base + 64 * j + lane, ntot - 1)];
+            double xv[ROWS];
+#pragma unroll
+            for (int j = 0; j < ROWS; ++j)
+                xv[j] = A.x[gi[j]];
+#pragma unroll
+            for (int j = 0; j < ROWS; ++j)
             {
-                int gi[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    gi[j] = dofs[min(base + 64 * j + lane, nloc - 1)];
-                double xv[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    xv[j] = A.x[gi[j]];
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
+                const int t = base + 64 * j + lane;
+                if (t < ntot)
                 {
-                    const int i = base + 64 * j + lane;
-                    if (i < nloc)
-                    {
-                        xs[h * ML + i] = xv[j];
-                        ys[h * ML + i] = 0.0;
-                    }
+                    const int pos = t < n0 ? t : ML + (t - n0);
+                    xs[pos] = xv[j];
+                    ys[pos] = 0.0;
                 }
             }
         }
         __syncthreads();
 
         // ------------------------------------------------------------ element phase
-        const bool have = half < n_here;
-        const int patch = have ? 2 * pair + half : 2 * pair; // a missing second patch re-reads the first (results dropped)
-        const bool active = have && le < A.patch_nel[patch];
-        const uint32_t *li = A.lidx + ((size_t)patch * NP) * PE + le;
         const double *xc = xs + half * ML;
-        uint32_t lpk[NP];
-#pragma unroll
-        for (int j = 0; j < NP; ++j)
-            lpk[j] = li[j * PE];
         auto lix_of = [&](int n) -> int { return (n & 1) ? static_cast<int>(lpk[n >> 1] >> 16) : static_cast<int>(lpk[n >> 1] & 0xFFFFu); };
         const double keep = active ? 1.0 : 0.0;
         double u[NN], out[NN];
@@ -634,29 +666,10 @@ namespace
             out[n] = 0.0;
         }
 
-        if constexpr (KIND == 0)
+        auto slice = [&](int q, const double (&g)[NM])
         {
-            const double *Gp = A.Gp + (size_t)patch * 3 * NQ * NQ * PE + le;
-#pragma unroll 1
-            for (int q = 0; q < NQ; ++q)
+            if constexpr (KIND == 0)
             {
-                double g[3 * NQ];
-#pragma unroll
-                for (int r = 0; r < NQ; ++r)
-                {
-                    if constexpr (UM)
-                    {
-                        g[3 * r + 0] = MU[(q * 3 + 0) * NQ + r];
-                        g[3 * r + 1] = MU[(q * 3 + 1) * NQ + r];
-                        g[3 * r + 2] = MU[(q * 3 + 2) * NQ + r];
-                    }
-                    else
-                    {
-                        g[3 * r + 0] = metric_load<NT>(&Gp[((q * 3 + 0) * NQ + r) * PE]);
-                        g[3 * r + 1] = metric_load<NT>(&Gp[((q * 3 + 1) * NQ + r) * PE]);
-                        g[3 * r + 2] = metric_load<NT>(&Gp[((q * 3 + 2) * NQ + r) * PE]);
-                    }
-                }
                 double pu[NB], du[NB], t0[NB], t1[NB];
 #pragma unroll
                 for (int l = 0; l < NB; ++l)
@@ -683,8 +696,8 @@ namespace
                         dx += P[r + NQ * l] * du[l];
                         dy += D[r + NQ * l] * pu[l];
                     }
-                    const double f0 = g[3 * r + 0] * dx + g[3 * r + 1] * dy;
-                    const double f1 = g[3 * r + 1] * dx + g[3 * r + 2] * dy;
+                    const double f0 = g[0 * NQ + r] * dx + g[1 * NQ + r] * dy;
+                    const double f1 = g[1 * NQ + r] * dx + g[2 * NQ + r] * dy;
 #pragma unroll
                     for (int l = 0; l < NB; ++l)
                     {
@@ -698,17 +711,8 @@ namespace
                     for (int k = 0; k < NB; ++k)
                         out[k + NB * l] += D[q + NQ * k] * t0[l] + P[q + NQ * k] * t1[l];
             }
-        }
-        else
-        {
-            const double *ap = A.aMp + (size_t)patch * NQ * NQ * PE + le;
-#pragma unroll 1
-            for (int q = 0; q < NQ; ++q)
+            else
             {
-                double am[NQ];
-#pragma unroll
-                for (int r = 0; r < NQ; ++r)
-                    am[r] = UM ? MU[q * NQ + r] : metric_load<NT>(&ap[(q * NQ + r) * PE]);
                 double pu[NB], t[NB];
 #pragma unroll
                 for (int l = 0; l < NB; ++l)
@@ -727,7 +731,7 @@ namespace
 #pragma unroll
                     for (int l = 0; l < NB; ++l)
                         val += P[r + NQ * l] * pu[l];
-                    val *= am[r];
+                    val *= g[r];
 #pragma unroll
                     for (int l = 0; l < NB; ++l)
                         t[l] += P[r + NQ * l] * val;
@@ -738,12 +742,21 @@ namespace
                     for (int k = 0; k < NB; ++k)
                         out[k + NB * l] += P[q + NQ * k] * t[l];
             }
+        };
+        if constexpr (!UM)
+            slice(0, g_first);
+        // (two slices per round trip were measured slower: more registers, same memory queues)
+#pragma unroll 1
+        for (int q = UM ? 0 : 1; q < NQ; ++q)
+        {
+            double g[NM];
+            load_slice(q, g);
+            slice(q, g);
         }
 
         // accumulate in colour phases (both patches at once: they use different halves of ys)
         {
             double *yc = ys + half * ML;
-            const int mycol = active ? A.colour[patch * PE + le] : -1;
             for (int c = 0; c < A.ncol; ++c)
             {
                 if (mycol == c)
@@ -758,37 +771,32 @@ namespace
 
         // ------------------------------------------------------------ write out
         const double c = A.omega; // the scale factor travels in the omega field
-        for (int h = 0; h < n_here; ++h)
+        const int *slot = A.slot_of + off;
+        for (int base = 0; base < ntot; base += 64 * ROWS)
         {
-            const int off = A.dof_off[2 * pair + h];
-            const int nloc = A.dof_off[2 * pair + h + 1] - off;
-            const int *dofs = A.dof_list + off;
-            const int *slot = A.slot_of + off;
-            for (int base = 0; base < nloc; base += 256)
+            int si[ROWS], gi[ROWS];
+            double y0[ROWS];
+#pragma unroll
+            for (int j = 0; j < ROWS; ++j)
             {
-                int si[4], gi[4];
-                double y0[4];
+                const int t = min(base + 64 * j + lane, ntot - 1);
+                si[j] = slot[t];
+                gi[j] = dofs[t];
+            }
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                {
-                    const int i = min(base + 64 * j + lane, nloc - 1);
-                    si[j] = slot[i];
-                    gi[j] = dofs[i];
-                }
+            for (int j = 0; j < ROWS; ++j)
+                y0[j] = (accumulate && si[j] < 0) ? A.y[gi[j]] : 0.0;
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    y0[j] = (accumulate && si[j] < 0) ? A.y[gi[j]] : 0.0;
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                {
-                    const int i = base + 64 * j + lane;
-                    if (i >= nloc)
-                        continue;
-                    if (si[j] < 0)
-                        A.y[gi[j]] = y0[j] + c * ys[h * ML + i];
-                    else
-                        A.part[si[j]] = c * ys[h * ML + i];
-                }
+            for (int j = 0; j < ROWS; ++j)
+            {
+                const int t = base + 64 * j + lane;
+                if (t >= ntot)
+                    continue;
+                const double val = c * ys[t < n0 ? t : ML + (t - n0)];
+                if (si[j] < 0)
+                    A.y[gi[j]] = y0[j] + val;
+                else
+                    A.part[si[j]] = val;
             }
         }
     }
