@@ -1,10 +1,13 @@
 """Runs one hot kernel a few times (for rocprofv3 counter passes).
 usage: run_kernel.py helm|ddh NX [REPS] [KERNEL]"""
 import math
+import os
 import sys
 from pathlib import Path
 
 import torch
+
+os.environ.setdefault("CUDDH_PLAN_AFFINE", "0")  # counters are collected on the general-geometry layout (the roofline figure)
 
 sys.path.insert(0, str(Path(__file__).resolve().parents[2]))
 import cuddhelmholtz_amd as cd  # noqa: E402
