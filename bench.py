@@ -249,7 +249,7 @@ def main() -> None:
                         f"({info['nel1d']}x{info['nel1d']} elements each), nt={info['nt']} RK2 steps x 5 WaveHoltz iterations per action",
             "g_ndof": ndof,
             "n_traces": n,
-            "ddh_kernel": {1: "workgroup-per-subdomain", 2: "wavefront-per-subdomain", 3: "wavefront-per-subdomain, DPP-folded FMAs", 4: "wavefront-per-subdomain, DPP-folded FMAs + 4x4x1 MFMA", 5: "wavefront-per-subdomain, dense 16x16 element matrix on MFMA (v_mfma_f32_16x16x4_f32)", 6: "wavefront per two subdomains (n_basis 8), DPP-folded FMAs"}.get(info["kernel"], str(info["kernel"])),
+            "ddh_kernel": {1: "workgroup-per-subdomain", 2: "wavefront-per-subdomain", 3: "wavefront-per-subdomain, DPP-folded FMAs", 4: "wavefront-per-subdomain, DPP-folded FMAs + 4x4x1 MFMA", 5: "wavefront-per-subdomain, dense 16x16 element matrix on MFMA (v_mfma_f32_16x16x4_f32)", 6: "wavefront per two subdomains (n_basis 8), DPP-folded FMAs", 7: "wavefront per two subdomains (n_basis 8), separable sweep"}.get(info["kernel"], str(info["kernel"])),
             "sharding": {"none": "single GPU",
                          "allreduce": f"{world} contiguous subdomain ranges, replicated trace vectors, one RCCL all-reduce of the trace vector per step",
                          "neighbour": f"{world} contiguous subdomain ranges, trace vectors partitioned by slot ownership, grouped RCCL "

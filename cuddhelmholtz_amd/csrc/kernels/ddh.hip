@@ -29,6 +29,7 @@ struct cuddh_ddh_plan
                 // 5 dense element matrix on the matrix cores (fp32, uniform geometry)
     int nodes;  // nb*nb*nel1d*nel1d
     float *Aop = nullptr; // kernel 5: element stiffness matrix as MFMA A operands, [4 k-steps][64 lanes]
+    float *Sep = nullptr; // kernel 7: [Ax | Ay | beta | gamma] of the separable nb = 8 sweep
 };
 
 namespace
@@ -570,9 +571,64 @@ namespace
         }
     }
 
-    template <typename Real, bool ASM>
+    // Separable form (kernel 7).  On the rectangles of a uniform_rect mesh the metric is diagonal and a product of 1-D
+    // factors, gx(k,l) = alpha_k beta_l, gz(k,l) = gamma_k delta_l, gy = 0, so the sweep  D^T (G (D u))  collapses to
+    //     z(k,l) = beta_l * sum_j Ax(k,j) u(j,l)  +  gamma_k * sum_j Ay(l,j) u(k,j),
+    // Ax = D^T diag(alpha) D, Ay = D^T diag(delta) D (8 x 8, built in double when the plan is created): ONE contraction
+    // per direction instead of two.  Sep = [Ax (k + 8 j) | Ay (l + 8 j) | beta | gamma].
+    template <bool ASM, typename Real>
+    __device__ inline void wave8_stiffness_sep(const Real (&w)[8], Real (&z)[8], const Real (&AxK)[8], const Real *__restrict__ Sep,
+                                               Real gamma, Real mR, Real mL, Real mU, Real mD, int lane)
+    {
+        const Real *Ay = Sep + 64, *beta = Sep + 128;
+        Real X[8], zz[8];
+        octet_contract_any<ASM>(w, AxK, X);
+#pragma unroll
+        for (int l = 0; l < 8; ++l)
+        {
+            Real s = Ay[l] * w[0];
+#pragma unroll
+            for (int j = 1; j < 8; ++j)
+                s += Ay[l + 8 * j] * w[j];
+            zz[l] = gamma * s + beta[l] * X[l];
+        }
+        if constexpr (ASM && sizeof(Real) == 4)
+        {
+            const float(&za)[4] = reinterpret_cast<const float(&)[4]>(zz[0]);
+            const float(&zb)[4] = reinterpret_cast<const float(&)[4]>(zz[4]);
+            float ra[4], rb[4];
+            row_neighbours_asm(za, mR, mL, ra);
+            row_neighbours_asm(zb, mR, mL, rb);
+#pragma unroll
+            for (int l = 0; l < 4; ++l)
+            {
+                z[l] = zz[l] + ra[l];
+                z[4 + l] = zz[4 + l] + rb[l];
+            }
+        }
+        else
+        {
+#pragma unroll
+            for (int l = 0; l < 8; ++l)
+            {
+                const Real from_right = dpp_read<ROW_SHL1>(zz[l]);
+                const Real from_left = dpp_read<ROW_SHR1>(zz[l]);
+                z[l] = zz[l] + (mR * from_right + mL * from_left);
+            }
+        }
+        {
+            const Real top = z[7], bottom = z[0];
+            const Real from_above = __shfl(bottom, (lane + 16) & 63, 64);
+            const Real from_below = __shfl(top, (lane + 48) & 63, 64);
+            z[7] = top + mU * from_above;
+            z[0] = bottom + mD * from_below;
+        }
+    }
+
+    template <typename Real, bool ASM, bool SEP>
     __global__ void __launch_bounds__(256) ddh_wave8_kernel(DdhArgs<Real> A, const Real *__restrict__ Dmat, const Real *__restrict__ filt,
-                                                           const Real *__restrict__ cs, const Real *__restrict__ sn)
+                                                           const Real *__restrict__ cs, const Real *__restrict__ sn,
+                                                           const Real *__restrict__ Sep)
     {
         const int lane = threadIdx.x & 63;
         const int s_first = A.dom_begin + 2 * (blockIdx.x * 4 + (threadIdx.x >> 6));
@@ -594,10 +650,15 @@ namespace
         {
             const int node = k + 8 * (l + 8 * el);
             const int d = sI[node];
-            const Real *g = A.G + 3 * ((size_t)node + 256 * (size_t)s);
-            gx[l] = g[0];
-            gy[l] = g[1];
-            gz[l] = g[2];
+            if constexpr (!SEP)
+            {
+                const Real *g = A.G + 3 * ((size_t)node + 256 * (size_t)s);
+                gx[l] = g[0];
+                gy[l] = g[1];
+                gz[l] = g[2];
+            }
+            else
+                gx[l] = gy[l] = gz[l] = 0;
             const Real ai = A.a[dbase + d], mi = A.m[dbase + d];
             invm[l] = Real(1) / (ai * ai * mi);
             Real f = 0, gg = 0, h = 0;
@@ -628,12 +689,23 @@ namespace
         }
 
         Real Dk[8], DTk[8];
+        Real gamma = 0;
 #pragma unroll
         for (int x = 0; x < 8; ++x)
         {
-            Dk[x] = Dmat[k + 8 * (k ^ x)];  // D(k, k^x)
-            DTk[x] = Dmat[(k ^ x) + 8 * k]; // D(k^x, k)
+            if constexpr (SEP)
+            {
+                Dk[x] = Sep[k + 8 * (k ^ x)]; // Ax(k, k^x)
+                DTk[x] = 0;
+            }
+            else
+            {
+                Dk[x] = Dmat[k + 8 * (k ^ x)];  // D(k, k^x)
+                DTk[x] = Dmat[(k ^ x) + 8 * k]; // D(k^x, k)
+            }
         }
+        if constexpr (SEP)
+            gamma = Sep[136 + k];
         const Real mR = (k == 7 && ex == 0) ? Real(1) : Real(0);
         const Real mL = (k == 0 && ex == 1) ? Real(1) : Real(0);
         const Real mU = (ey == 0) ? Real(1) : Real(0);
@@ -662,7 +734,10 @@ namespace
                 const Real kw = filt[it];
                 Real z[8], ph[8], qh[8];
 
-                wave8_stiffness<ASM>(p, z, gx, gy, gz, Dk, DTk, Dmat, mR, mL, mU, mD, lane);
+                if constexpr (SEP)
+                    wave8_stiffness_sep<ASM>(p, z, Dk, Sep, gamma, mR, mL, mU, mD, lane);
+                else
+                    wave8_stiffness<ASM>(p, z, gx, gy, gz, Dk, DTk, Dmat, mR, mL, mU, mD, lane);
 #pragma unroll
                 for (int l = 0; l < 8; ++l)
                 {
@@ -671,7 +746,10 @@ namespace
                     qh[l] = q[l] + half_dt * dq;
                     p[l] -= dt * qh[l];
                 }
-                wave8_stiffness<ASM>(ph, z, gx, gy, gz, Dk, DTk, Dmat, mR, mL, mU, mD, lane);
+                if constexpr (SEP)
+                    wave8_stiffness_sep<ASM>(ph, z, Dk, Sep, gamma, mR, mL, mU, mD, lane);
+                else
+                    wave8_stiffness<ASM>(ph, z, gx, gy, gz, Dk, DTk, Dmat, mR, mL, mU, mD, lane);
 #pragma unroll
                 for (int l = 0; l < 8; ++l)
                 {
@@ -899,11 +977,12 @@ namespace
     }
 
     // is the metric tensor of every element of every subdomain identical to that of (subdomain 0, element 0)?
-    __global__ void __launch_bounds__(256) ddh_uniform_check_kernel(long long n_nodes_total, const float *__restrict__ G, int *__restrict__ bad)
+    __global__ void __launch_bounds__(256) ddh_uniform_check_kernel(long long n_nodes_total, int nodes_per_elem, const float *__restrict__ G,
+                                                                    int *__restrict__ bad)
     {
         for (long long t = blockIdx.x * 256LL + threadIdx.x; t < n_nodes_total; t += gridDim.x * 256LL)
         {
-            const int node = static_cast<int>(t % 16); // node within its element
+            const int node = static_cast<int>(t % nodes_per_elem); // node within its element
             const float *g = G + 3 * t, *g0 = G + 3 * node;
             if (g[0] != g0[0] || g[1] != g0[1] || g[2] != g0[2])
                 atomicExch(bad, 1);
@@ -1171,7 +1250,7 @@ namespace
             return static_cast<int>(e);
         (void)hipMemset(flag, 0, sizeof(int));
         const long long n_nodes = 256LL * d.n_domains;
-        hipLaunchKernelGGL(ddh_uniform_check_kernel, dim3(stream_grid(n_nodes, 256)), dim3(256), 0, nullptr, n_nodes, G, flag);
+        hipLaunchKernelGGL(ddh_uniform_check_kernel, dim3(stream_grid(n_nodes, 256)), dim3(256), 0, nullptr, n_nodes, 16, G, flag);
         int bad = 1;
         e = hipMemcpy(&bad, flag, sizeof(int), hipMemcpyDeviceToHost);
         (void)hipFree(flag);
@@ -1233,6 +1312,74 @@ namespace
         return static_cast<int>(e);
     }
 
+    // kernel 7 tables: needs one metric tensor for all elements, diagonal (gy == 0) and a product of 1-D factors
+    // (rectangles).  Returns 0 on success, -1 when the geometry does not qualify, > 0 on a HIP error.
+    int build_separable_tables(cuddh_ddh_plan *p)
+    {
+        const cuddh_ddh_desc &d = p->d;
+        const float *G = static_cast<const float *>(d.G);
+        int *flag = nullptr;
+        hipError_t e = hipMalloc(&flag, sizeof(int));
+        if (e != hipSuccess)
+            return static_cast<int>(e);
+        (void)hipMemset(flag, 0, sizeof(int));
+        const long long n_nodes = 256LL * d.n_domains;
+        hipLaunchKernelGGL(ddh_uniform_check_kernel, dim3(stream_grid(n_nodes, 256)), dim3(256), 0, nullptr, n_nodes, 64, G, flag);
+        int bad = 1;
+        e = hipMemcpy(&bad, flag, sizeof(int), hipMemcpyDeviceToHost);
+        (void)hipFree(flag);
+        if (e != hipSuccess)
+            return static_cast<int>(e);
+        if (bad)
+            return -1;
+        float hD[64], hG[192];
+        e = hipMemcpy(hD, d.D, sizeof hD, hipMemcpyDeviceToHost);
+        if (e == hipSuccess)
+            e = hipMemcpy(hG, G, sizeof hG, hipMemcpyDeviceToHost);
+        if (e != hipSuccess)
+            return static_cast<int>(e);
+        auto Dm = [&](int a, int b) { return static_cast<double>(hD[a + 8 * b]); }; // D(a,b)
+        auto g = [&](int c, int k, int l) { return static_cast<double>(hG[3 * (k + 8 * l) + c]); };
+        double scale = 0.0;
+        for (int n = 0; n < 64; ++n)
+            scale = std::max(scale, std::fabs(static_cast<double>(hG[3 * n])) + std::fabs(static_cast<double>(hG[3 * n + 2])));
+        double alpha[8], beta[8], gamma[8], delta[8];
+        for (int i = 0; i < 8; ++i)
+        {
+            alpha[i] = g(0, i, 0);
+            beta[i] = g(0, 0, i) / g(0, 0, 0);
+            gamma[i] = g(2, i, 0) / g(2, 0, 0);
+            delta[i] = g(2, 0, i);
+        }
+        for (int l = 0; l < 8; ++l)
+            for (int k = 0; k < 8; ++k)
+                if (std::fabs(g(1, k, l)) > 1e-6 * scale || std::fabs(g(0, k, l) - alpha[k] * beta[l]) > 1e-6 * scale ||
+                    std::fabs(g(2, k, l) - gamma[k] * delta[l]) > 1e-6 * scale)
+                    return -1;
+        float hS[144];
+        for (int a = 0; a < 8; ++a)
+            for (int b = 0; b < 8; ++b)
+            {
+                double ax = 0.0, ay = 0.0;
+                for (int i = 0; i < 8; ++i)
+                {
+                    ax += Dm(i, a) * alpha[i] * Dm(i, b);
+                    ay += Dm(i, a) * delta[i] * Dm(i, b);
+                }
+                hS[a + 8 * b] = static_cast<float>(ax);
+                hS[64 + a + 8 * b] = static_cast<float>(ay);
+            }
+        for (int i = 0; i < 8; ++i)
+        {
+            hS[128 + i] = static_cast<float>(beta[i]);
+            hS[136 + i] = static_cast<float>(gamma[i]);
+        }
+        e = hipMalloc(reinterpret_cast<void **>(&p->Sep), sizeof hS);
+        if (e == hipSuccess)
+            e = hipMemcpy(p->Sep, hS, sizeof hS, hipMemcpyHostToDevice);
+        return static_cast<int>(e);
+    }
+
     template <typename Real>
     int apply(const cuddh_ddh_plan *plan, int dom_begin, int dom_end, const double *x, double *y, int zero_y, const Real *lambda,
               Real *update, void *stream)
@@ -1288,12 +1435,21 @@ namespace
                 return launch_status();
             }
         }
-        if (plan->kernel == 6)
+        if (plan->kernel == 6 || plan->kernel == 7)
         {
             const dim3 grid((n_local + 7) / 8), block(256); // four wavefronts per workgroup, two subdomains per wavefront
             const Real *D = static_cast<const Real *>(d.D), *fl = static_cast<const Real *>(d.wh_filter);
             const Real *cs = static_cast<const Real *>(d.cs), *sn = static_cast<const Real *>(d.sn);
-            hipLaunchKernelGGL((ddh_wave8_kernel<Real, sizeof(Real) == 4>), grid, block, 0, st, A, D, fl, cs, sn);
+            if constexpr (sizeof(Real) == 4)
+            {
+                if (plan->kernel == 7)
+                    hipLaunchKernelGGL((ddh_wave8_kernel<float, true, true>), grid, block, 0, st, A, D, fl, cs, sn, plan->Sep);
+                else
+                    hipLaunchKernelGGL((ddh_wave8_kernel<float, true, false>), grid, block, 0, st, A, D, fl, cs, sn, plan->Sep);
+            }
+            else
+                hipLaunchKernelGGL((ddh_wave8_kernel<double, false, false>), grid, block, 0, st, A, D, fl, cs, sn,
+                                   static_cast<const double *>(nullptr));
             return launch_status();
         }
         if (plan->kernel >= 2)
@@ -1367,7 +1523,7 @@ extern "C"
     int cuddh_hip_ddh_plan_create(cuddh_ddh_plan **out, const cuddh_ddh_desc *desc, int is_f64, int kernel)
     {
         *out = nullptr;
-        if (!desc || desc->nb < 2 || desc->nb > 10 || desc->nel1d < 1 || kernel < 0 || kernel > 6)
+        if (!desc || desc->nb < 2 || desc->nb > 10 || desc->nel1d < 1 || kernel < 0 || kernel > 7)
             return static_cast<int>(hipErrorInvalidValue);
         const int nodes = desc->nb * desc->nb * desc->nel1d * desc->nel1d;
         if (nodes > 256)
@@ -1381,7 +1537,7 @@ extern "C"
 
         const bool wave_shape = (desc->nb == 4 && desc->nel1d == 4);
         const bool wave8_shape = (desc->nb == 8 && desc->nel1d == 2);
-        if ((kernel >= 2 && kernel <= 5 && !wave_shape) || (kernel == 6 && !wave8_shape))
+        if ((kernel >= 2 && kernel <= 5 && !wave_shape) || (kernel >= 6 && !wave8_shape) || (kernel == 7 && is_f64))
         {
             delete p;
             return static_cast<int>(hipErrorInvalidValue);
@@ -1397,10 +1553,22 @@ extern "C"
             }
             if (!bad)
                 p->kernel = 6;
-            else if (kernel == 6)
+            else if (kernel >= 6)
             {
                 delete p;
                 return static_cast<int>(hipErrorInvalidValue);
+            }
+            // kernel 7 (one contraction per direction) needs fp32 and the rectangles of a uniform mesh
+            if (!bad && !is_f64 && (kernel == 0 || kernel == 7))
+            {
+                const int err7 = build_separable_tables(p);
+                if (err7 == 0)
+                    p->kernel = 7;
+                else if (kernel == 7)
+                {
+                    delete p;
+                    return err7 > 0 ? err7 : static_cast<int>(hipErrorInvalidValue);
+                }
             }
         }
         if (wave_shape && kernel != 1)
@@ -1445,6 +1613,8 @@ extern "C"
     {
         if (plan && plan->Aop)
             (void)hipFree(plan->Aop);
+        if (plan && plan->Sep)
+            (void)hipFree(plan->Sep);
         delete plan;
         return 0;
     }

@@ -218,10 +218,13 @@ typedef struct cuddh_ddh_plan cuddh_ddh_plan;
  *             v_mfma_f32_16x16x4_f32 (fp32; needs the same metric tensor in every element, which
  *             plan_create verifies on the device; what auto picks when it applies),
  *         6 = n_basis == 8 (2x2 elements, the reference's other supported shape): one wavefront per TWO
- *             subdomains, registers + DPP over the eight lanes of a column octet (what auto picks for nb == 8). */
+ *             subdomains, registers + DPP over the eight lanes of a column octet,
+ *         7 = 6 in separable form (fp32): on the rectangles of a uniform mesh the metric is diagonal and a product of
+ *             1-D factors, so a sweep needs ONE 8x8 contraction per direction (D^T diag D precomputed) instead of two
+ *             (plan_create verifies the geometry; what auto picks for nb == 8 when it applies). */
 int cuddh_hip_ddh_plan_create(cuddh_ddh_plan **plan, const cuddh_ddh_desc *desc, int is_f64, int kernel);
 int cuddh_hip_ddh_plan_destroy(cuddh_ddh_plan *plan);
-/* which kernel the plan resolved to (1..6) */
+/* which kernel the plan resolved to (1..7) */
 int cuddh_hip_ddh_plan_kernel(const cuddh_ddh_plan *plan);
 
 /* source/DDH.cpp:111-321 (ddh_action + stiffness).  x: forcing [F;G] (2*g_ndof

@@ -440,7 +440,7 @@ def test_ddh_fp64_entry_points(cuda, nx, nb, kernel):
     assert torch.equal(upd, full)
 
 
-@pytest.mark.parametrize("nx,nb,kernel", [(8, 4, 1), (8, 4, 2), (8, 4, 3), (8, 4, 4), (8, 4, 5), (16, 4, 2), (16, 4, 3), (16, 4, 4), (16, 4, 5), (8, 8, 1), (8, 8, 6)])
+@pytest.mark.parametrize("nx,nb,kernel", [(8, 4, 1), (8, 4, 2), (8, 4, 3), (8, 4, 4), (8, 4, 5), (16, 4, 2), (16, 4, 3), (16, 4, 4), (16, 4, 5), (8, 8, 1), (8, 8, 6), (8, 8, 7)])
 def test_ddh_fp32_reference_precision(cuda, nx, nb, kernel):
     import torch
 
