@@ -225,7 +225,8 @@ namespace
     // Every workgroup sums the same <= MAX_PARTIALS partials in the same order, so all of them use the same h.
     template <typename T>
     __global__ void __launch_bounds__(BLOCK) mgs_stage_kernel(int n, T *__restrict__ w, const T *__restrict__ vprev, const T *__restrict__ vnext,
-                                                              const T *__restrict__ pin, int npin, T *__restrict__ pout, T *__restrict__ hout)
+                                                              const T *__restrict__ pin, int npin, T *__restrict__ pout, T *__restrict__ hout,
+                                                              int vectorised)
     {
         __shared__ T h_sh;
         T h = T(0);
@@ -245,7 +246,36 @@ namespace
             h = h_sh;
         }
         T acc = T(0);
-        for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK)
+        using V = typename Pack<T>::type;
+        constexpr int N = Pack<T>::N;
+        const int tid = blockIdx.x * BLOCK + threadIdx.x, stride = gridDim.x * BLOCK;
+        int done = 0;
+        if (vectorised)
+        {
+            // three streams in, one out, 16 bytes per lane and access
+            const int nv = n / N;
+            for (int i = tid; i < nv; i += stride)
+            {
+                V wv = reinterpret_cast<const V *>(w)[i], pv = wv, nvv = wv;
+                if (vprev)
+                    pv = reinterpret_cast<const V *>(vprev)[i];
+                if (vnext)
+                    nvv = reinterpret_cast<const V *>(vnext)[i];
+                T *we = reinterpret_cast<T *>(&wv);
+                const T *pe = reinterpret_cast<const T *>(&pv), *ne = reinterpret_cast<const T *>(&nvv);
+#pragma unroll
+                for (int c = 0; c < N; ++c)
+                {
+                    if (vprev)
+                        we[c] -= h * pe[c];
+                    acc += we[c] * (vnext ? ne[c] : we[c]);
+                }
+                if (vprev)
+                    reinterpret_cast<V *>(w)[i] = wv;
+            }
+            done = nv * N;
+        }
+        for (int i = done + tid; i < n; i += stride)
         {
             T wi = w[i];
             if (vprev)
@@ -263,7 +293,8 @@ namespace
 
     // nrm = sqrt(sum(pin));  *hout = nrm;  w <- w / nrm
     template <typename T>
-    __global__ void __launch_bounds__(BLOCK) mgs_finish_kernel(int n, T *__restrict__ w, const T *__restrict__ pin, int npin, T *__restrict__ hout)
+    __global__ void __launch_bounds__(BLOCK) mgs_finish_kernel(int n, T *__restrict__ w, const T *__restrict__ pin, int npin, T *__restrict__ hout,
+                                                               int vectorised)
     {
         __shared__ T nrm_sh;
         T a = T(0);
@@ -278,7 +309,25 @@ namespace
         }
         __syncthreads();
         const T nrm = nrm_sh;
-        for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK)
+        using V = typename Pack<T>::type;
+        constexpr int N = Pack<T>::N;
+        const int tid = blockIdx.x * BLOCK + threadIdx.x, stride = gridDim.x * BLOCK;
+        int done = 0;
+        if (vectorised)
+        {
+            const int nv = n / N;
+            for (int i = tid; i < nv; i += stride)
+            {
+                V wv = reinterpret_cast<const V *>(w)[i];
+                T *we = reinterpret_cast<T *>(&wv);
+#pragma unroll
+                for (int c = 0; c < N; ++c)
+                    we[c] = we[c] / nrm;
+                reinterpret_cast<V *>(w)[i] = wv;
+            }
+            done = nv * N;
+        }
+        for (int i = done + tid; i < n; i += stride)
             w[i] = w[i] / nrm;
     }
 
@@ -292,7 +341,8 @@ namespace
     int launch_mgs_stage(int n, T *w, const T *vprev, const T *vnext, const T *pin, T *pout, T *hout, void *stream)
     {
         const int g = mgs_grid(n);
-        hipLaunchKernelGGL((mgs_stage_kernel<T>), dim3(g), dim3(BLOCK), 0, as_stream(stream), n, w, vprev, vnext, pin, g, pout, hout);
+        const int vec = aligned16(w) && (!vprev || aligned16(vprev)) && (!vnext || aligned16(vnext));
+        hipLaunchKernelGGL((mgs_stage_kernel<T>), dim3(g), dim3(BLOCK), 0, as_stream(stream), n, w, vprev, vnext, pin, g, pout, hout, vec);
         return launch_status();
     }
 
@@ -300,7 +350,7 @@ namespace
     int launch_mgs_finish(int n, T *w, const T *pin, T *hout, void *stream)
     {
         const int g = mgs_grid(n);
-        hipLaunchKernelGGL((mgs_finish_kernel<T>), dim3(g), dim3(BLOCK), 0, as_stream(stream), n, w, pin, g, hout);
+        hipLaunchKernelGGL((mgs_finish_kernel<T>), dim3(g), dim3(BLOCK), 0, as_stream(stream), n, w, pin, g, hout, aligned16(w) ? 1 : 0);
         return launch_status();
     }
 
