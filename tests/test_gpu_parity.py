@@ -623,3 +623,38 @@ def test_poisson_pipeline(cuda):
     uo += Go
     assert out.success and info["success"]
     assert rel(u.cpu().numpy(), uo) < 1e-7
+
+
+# ------------------------------------------------------------------ refined unstructured mesh (irregular gather/scatter)
+def test_fused_apply_on_refined_unstructured_mesh(cuda):
+    """The reference's unstructured fixture refined twice (1,904 quads, every element with its own metric tensor):
+    the fused apply and the single-operator plans against the oracle."""
+    import torch
+
+    import cuddhelmholtz_amd as cd
+    from cuddhelmholtz_amd.meshtools import refine_quads
+
+    xy, elems = refine_quads(*load_unstructured_square(), times=2)
+    assert len(elems) == 119 * 16
+    pm, om = cd.Mesh2D.from_vertices(xy, elems), oracle.Mesh(xy, elems)
+    nb = 4
+    fem = cd.H1Space(pm, cd.Basis(nb))
+    d = oracle.Discretization(om, nb)
+    assert fem.size() == d.ndof
+    faces = pm.boundary_edges()
+    fs = cd.FaceSpace(fem, faces)
+    ofs = oracle.FaceSpaceO(d, list(faces))
+    rng = np.random.default_rng(77)
+    a2, ax = 0.5 + rng.random(d.ndof), 0.5 + rng.random(ofs.size)
+    omega = 11.0
+    A = cd.HelmholtzOperator(omega, to_dev(torch, a2, cuda), to_dev(torch, ax, cuda), fem, fs)
+    assert A.fused() and A.bytes_affine() == 0  # no two elements share a metric tensor here
+    xh = rng.standard_normal(2 * d.ndof)
+    x = to_dev(torch, xh, cuda)
+    y = torch.empty_like(x)
+    A.action(x, y)
+    ref = oracle.helmholtz_apply(d, oracle.Stiffness(d), oracle.Mass(d, a2), oracle.FaceMass(ofs, ax), ofs, omega, xh)
+    assert rel(y.cpu().numpy(), ref) < 1e-12
+    yS = torch.empty(d.ndof, dtype=torch.float64, device=cuda)
+    cd.StiffnessMatrix(fem).action(x[: d.ndof], yS)
+    assert rel(yS.cpu().numpy(), oracle.Stiffness(d).apply(xh[: d.ndof])) < 1e-12
