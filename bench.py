@@ -10,13 +10,17 @@ reading reference DDH supports), fp32 local solves (the reference's precision), 
            against the current Krylov basis (k cycles 0..19).  The once-per-20-steps restart
            bookkeeping (host triangular solve, true-residual matvec) is not in the loop.
   value  = 2 * g_ndof * steps / seconds   [DoF.iter/s], whole job, MAX time over ranks.
-  N > 1  = subdomains split into contiguous ranges, one per rank; every rank keeps the whole
-           (26 MB) trace vector, local solves write only their own slots, one RCCL all-reduce
-           (sum with zeros) per step reassembles it.  Total work fixed -> "strong" scaling.
+  N > 1  = subdomains split into contiguous ranges, one per rank (total work fixed -> "strong"
+           scaling).  Default: trace/Krylov vectors partitioned by slot ownership, the traces a
+           rank writes for another rank's subdomains go to that (neighbouring) rank by grouped
+           RCCL send/recv, every inner product is all-reduced (cuddhelmholtz_amd/dist.py).  The
+           assembly is cross-checked at start-up against the replicated-vector form (one all-reduce
+           of the 27 MB trace vector per step, --exchange allreduce), which is also the fallback.
 
 Extra objects on the same JSON line:
-  roofline     = the global operator apply (fused complex Helmholtz apply on the same mesh),
-                 the HBM-bound kernel of the path: algorithmic bytes / measured launch time.
+  roofline     = the global operator apply (fused complex Helmholtz apply on the same mesh, in the
+                 GENERAL-geometry layout), the HBM-bound kernel of the path: algorithmic bytes /
+                 measured launch time; roofline.affine = labelled timing of the uniform-mesh form.
   ddh_kernel   = the dominant kernel of `value` (not HBM-bound): fp32 FLOP rate vs vector peak.
   cpu_baseline = the oracle's restatement of the local solves timed on the host cores on a
                  bounded sample of subdomains (rank 0, N = 1 only).
