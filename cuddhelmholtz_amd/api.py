@@ -425,9 +425,15 @@ def gmres(n: int, x, A, b, m: int, maxit: int, tol: float = 1e-6, verbose: int =
         dev = x.device
         errors = []
 
+        views = {}
+
         def wrap(ptr, count):
-            # view of library-owned device memory as a tensor (no copy)
-            return torch.as_tensor(_DevArray(ptr, count, is64), device=dev)
+            # view of library-owned device memory as a tensor (no copy); the solver reuses a handful of addresses
+            key = (ptr, count)
+            t = views.get(key)
+            if t is None:
+                t = views[key] = torch.as_tensor(_DevArray(ptr, count, is64), device=dev)
+            return t
 
         def cb(ctx, xp, yp):
             try:
