@@ -54,7 +54,7 @@ struct cuddh_helmholtz_plan
     // basis tables
     double *PS = nullptr, *DS = nullptr, *PM = nullptr, *PF = nullptr;
     // patch-border dofs
-    int *shared_dof = nullptr, *shared_off = nullptr, *shared_slots = nullptr;
+    int *shared_dof = nullptr, *shared_off = nullptr; // border dof j sums the contiguous slots shared_off[j] .. shared_off[j+1]
     double *part = nullptr; // [2][n_slots]
     size_t bytes_alg = 0, bytes_actual = 0;
     int streaming = 0; // metric loads carry the non-temporal hint (plans larger than the infinity cache)
@@ -416,7 +416,7 @@ namespace
     }
 
     __global__ void __launch_bounds__(256) helm_border_kernel(int n_shared, int ndof, int n_slots, const int *__restrict__ shared_dof,
-                                                             const int *__restrict__ shared_off, const int *__restrict__ shared_slots,
+                                                             const int *__restrict__ shared_off,
                                                              const double *__restrict__ part, double *__restrict__ y)
     {
         for (int j = blockIdx.x * 256 + threadIdx.x; j < n_shared; j += gridDim.x * 256)
@@ -424,7 +424,7 @@ namespace
             double su = 0.0, sv = 0.0;
             for (int t = shared_off[j]; t < shared_off[j + 1]; ++t)
             {
-                const int s = shared_slots[t];
+                const int s = t; // the slots of one dof are contiguous, in patch order
                 su += part[s];
                 sv += part[n_slots + s];
             }
@@ -802,7 +802,7 @@ namespace
     }
 
     __global__ void __launch_bounds__(256) op_border_kernel(int n_shared, int accumulate, const int *__restrict__ shared_dof,
-                                                           const int *__restrict__ shared_off, const int *__restrict__ shared_slots,
+                                                           const int *__restrict__ shared_off,
                                                            const double *__restrict__ part, double *__restrict__ y)
     {
         for (int j = blockIdx.x * 256 + threadIdx.x; j < n_shared; j += gridDim.x * 256)
@@ -810,7 +810,7 @@ namespace
             const int g = shared_dof[j];
             double s = accumulate ? y[g] : 0.0;
             for (int t = shared_off[j]; t < shared_off[j + 1]; ++t)
-                s += part[shared_slots[t]];
+                s += part[t]; // contiguous slots, patch order
             y[g] = s;
         }
     }
@@ -873,7 +873,7 @@ extern "C"
             return 0;
         void *ptrs[] = {p->dof_off, p->dof_list, p->slot_of, p->patch_nel, p->lidx, p->colour, p->Gp, p->aMp, p->Gu, p->au, p->face_off,
                         p->face_lidx, p->face_id, p->face_col, p->PS, p->DS, p->PM, p->PF, p->shared_dof, p->shared_off,
-                        p->shared_slots, p->part};
+                        p->part};
         for (void *q : ptrs)
             if (q)
                 (void)hipFree(q);
@@ -1041,7 +1041,7 @@ extern "C"
             }
         const int n_shared = static_cast<int>(shared_dof.size());
         const int n_slots = shared_off.back();
-        std::vector<int> slot_of(dof_list.size(), -1), shared_slots(n_slots), fill(shared_off.begin(), shared_off.end() - 1);
+        std::vector<int> slot_of(dof_list.size(), -1), fill(shared_off.begin(), shared_off.end() - 1);
         for (size_t i = 0; i < dof_list.size(); ++i)
         {
             const int j = shared_index[dof_list[i]];
@@ -1049,7 +1049,6 @@ extern "C"
             {
                 const int s = fill[j]++;
                 slot_of[i] = s;        // slots of one dof are contiguous and ordered by patch
-                shared_slots[s] = s;
             }
         }
         p->n_shared = n_shared;
@@ -1074,7 +1073,6 @@ extern "C"
         ok(upload(&p->face_col, face_col));
         ok(upload(&p->shared_dof, shared_dof));
         ok(upload(&p->shared_off, shared_off));
-        ok(upload(&p->shared_slots, shared_slots));
         if (nqS > 0)
         {
             ok(upload_raw(&p->PS, h_PS, (size_t)nqS * nb));
@@ -1127,7 +1125,7 @@ extern "C"
         for (int s : slot_of)
             exclusive += s < 0;
         p->bytes_actual = (size_t)nG * 8 + (size_t)nA * 8 + lidx.size() * 4 + colour.size() + dof_list.size() * (4 + 4 + 16) +
-                          exclusive * 16 + (size_t)n_slots * (16 + 16 + 4) + (size_t)n_shared * (16 + 8) +
+                          exclusive * 16 + (size_t)n_slots * (16 + 16) + (size_t)n_shared * (16 + 8) +
                           (size_t)n_faces * ((size_t)nqF * 8 + (size_t)nb * 2 + 5);
         if (p->Gu || p->au) // SURVEY 8d's "affine" figure: the uniform metric arrays are not traffic
             p->bytes_affine = p->bytes_alg - (size_t)n_elem * ((p->Gu ? (size_t)3 * nqS * nqS * 8 : 0) + (p->au ? (size_t)nqM * nqM * 8 : 0));
@@ -1180,7 +1178,7 @@ extern "C"
         if (p->n_shared > 0)
         {
             hipLaunchKernelGGL(op_border_kernel, dim3(stream_grid(p->n_shared, 256)), dim3(256), 0, st, p->n_shared, accumulate,
-                               p->shared_dof, p->shared_off, p->shared_slots, p->part, y);
+                               p->shared_dof, p->shared_off, p->part, y);
             err = launch_status();
         }
         return err;
@@ -1210,7 +1208,7 @@ extern "C"
         if (p->n_shared > 0)
         {
             hipLaunchKernelGGL(helm_border_kernel, dim3(stream_grid(p->n_shared, 256)), dim3(256), 0, st, p->n_shared, p->ndof, p->n_slots,
-                               p->shared_dof, p->shared_off, p->shared_slots, p->part, y);
+                               p->shared_dof, p->shared_off, p->part, y);
             err = launch_status();
         }
         return err;
