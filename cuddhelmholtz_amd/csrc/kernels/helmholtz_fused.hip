@@ -94,7 +94,7 @@ namespace
     // and exchanged with ds_bpermute, three role-specialised wavefronts per patch, touch-prefetch of the metric block.
     // UG: the stiffness metric is the same in every element and comes from the uniform table GU (scalar loads)
     template <int NB, int NQS, int NQM, bool NT, bool UG>
-    __global__ void __launch_bounds__(64, (NB >= 5 ? 2 : 4)) helm_patch_kernel(HelmArgs A, const double *__restrict__ PS, const double *__restrict__ DS,
+    __global__ void __launch_bounds__(64, (NB >= 5 ? 2 : ((NB == 4 && !UG) ? 3 : 4))) helm_patch_kernel(HelmArgs A, const double *__restrict__ PS, const double *__restrict__ DS,
                                                            const double *__restrict__ PM, const double *__restrict__ PF,
                                                            const double *__restrict__ GU)
     {
@@ -131,7 +131,9 @@ namespace
         for (int j = 0; j < NP; ++j)
             lpk[j] = li[j * PE];
         const int mycol = active ? A.colour[patch * PE + le] : -1;
-        constexpr bool PRE = !UG && NB <= 3; // from n_basis 4 on, holding the slice across the gather costs spills
+        // n_basis 4, general layout: 153 VGPRs at 3 waves/SIMD (no spills, first slice prefetched) measured faster than
+        // 128 VGPRs with 8 spilled at 4 waves/SIMD (1024^2: 402 vs 420 us; irregular 0.49 M quads: 187 vs 222 us)
+        constexpr bool PRE = !UG && NB <= 4;
         double g_first[3 * NQS];
         if constexpr (PRE)
         {
