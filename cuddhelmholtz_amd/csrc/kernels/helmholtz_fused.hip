@@ -588,7 +588,7 @@ namespace
     // every metric load instruction still fetches 2 x 256 contiguous bytes and no lane idles.
     // UM: the metric array of this operator is the same in every element and comes from the uniform table MU
     template <int NB, int NQ, int KIND, bool NT, bool UM>
-    __global__ void __launch_bounds__(64, (NB >= 5 ? 2 : 4)) op_patch_kernel(HelmArgs A, int accumulate, const double *__restrict__ P,
+    __global__ void __launch_bounds__(64, (NB >= 5 ? 2 : ((NB == 4 && KIND == 0 && !UM) ? 3 : 4))) op_patch_kernel(HelmArgs A, int accumulate, const double *__restrict__ P,
                                                                              const double *__restrict__ D, const double *__restrict__ MU)
     {
         constexpr int NN = NB * NB, NP = (NN + 1) / 2;
