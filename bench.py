@@ -316,6 +316,29 @@ def helmholtz_roofline(cd, torch, dev, fem, mesh, omega, ndof):
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) * 1e-3 / reps
 
+    # attainable HBM rate of this box, measured: a plain device copy through the product's own copy kernel
+    from cuddhelmholtz_amd import _native as N
+
+    n_copy = 1 << 27  # 1 GiB of doubles in, 1 GiB out
+    src = torch.empty(n_copy, dtype=torch.float64, device=dev).fill_(1.0)
+    dst = torch.empty_like(src)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def copy_once():
+        N.check(N.lib.cuddh_hip_copy_f64(n_copy, C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), st))
+
+    for _ in range(3):
+        copy_once()
+    torch.cuda.synchronize()
+    c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    c0.record()
+    for _ in range(10):
+        copy_once()
+    c1.record()
+    torch.cuda.synchronize()
+    copy_gbs = 2.0 * 8.0 * n_copy * 10 / (c0.elapsed_time(c1) * 1e-3) / 1e9
+    del src, dst
+
     # the roofline figure is stated on the GENERAL-geometry layout: the plan is told not to exploit that a
     # uniform_rect mesh has one metric tensor for all elements; the affine form is timed separately and labelled
     prev = os.environ.get("CUDDH_PLAN_AFFINE")
@@ -353,6 +376,8 @@ def helmholtz_roofline(cd, torch, dev, fem, mesh, omega, ndof):
         "peak": HBM_PEAK_GBS,
         "unit": "GB/s",
         "frac": gbs / HBM_PEAK_GBS,
+        "copy_ceiling": copy_gbs,  # measured in this run: device copy of 1 GiB, read + write bytes / time
+        "frac_of_copy_ceiling": gbs / copy_gbs,
         "traffic": traffic,
         "algorithmic_bytes": b_alg,
         "layout_bytes": A.bytes_per_apply(True),

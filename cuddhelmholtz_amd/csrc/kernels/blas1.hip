@@ -45,7 +45,31 @@ namespace
         if (vectorised)
         {
             const int nv = n / N;
-            for (int i = tid; i < nv; i += stride)
+            int i = tid;
+            // four independent 16-byte accesses per stream in flight per thread, then the single-access remainder
+            for (; i + 3 * stride < nv; i += 4 * stride)
+            {
+                V xv[4], yv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                {
+                    if (READ_X)
+                        xv[u] = reinterpret_cast<const V *>(x)[i + u * stride];
+                    if (READ_Y)
+                        yv[u] = reinterpret_cast<const V *>(y)[i + u * stride];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                {
+                    T *xe = reinterpret_cast<T *>(&xv[u]);
+                    T *ye = reinterpret_cast<T *>(&yv[u]);
+#pragma unroll
+                    for (int c = 0; c < N; ++c)
+                        ye[c] = f(READ_X ? xe[c] : T(0), READ_Y ? ye[c] : T(0));
+                    reinterpret_cast<V *>(y)[i + u * stride] = yv[u];
+                }
+            }
+            for (; i < nv; i += stride)
             {
                 V xv, yv;
                 if (READ_X)
@@ -159,10 +183,8 @@ namespace
         if (vectorised)
         {
             const int nv = n / N;
-            for (int i = tid; i < nv; i += stride)
+            auto term = [&](const V &xv, const V &yv)
             {
-                const V xv = reinterpret_cast<const V *>(x)[i];
-                const V yv = reinterpret_cast<const V *>(y)[i];
                 const T *xe = reinterpret_cast<const T *>(&xv);
                 const T *ye = reinterpret_cast<const T *>(&yv);
 #pragma unroll
@@ -176,7 +198,23 @@ namespace
                         acc += d * d;
                     }
                 }
+            };
+            int i = tid;
+            for (; i + 3 * stride < nv; i += 4 * stride) // four independent accesses per stream in flight
+            {
+                V xv[4], yv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                {
+                    xv[u] = reinterpret_cast<const V *>(x)[i + u * stride];
+                    yv[u] = reinterpret_cast<const V *>(y)[i + u * stride];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    term(xv[u], yv[u]);
             }
+            for (; i < nv; i += stride)
+                term(reinterpret_cast<const V *>(x)[i], reinterpret_cast<const V *>(y)[i]);
             done = nv * N;
         }
         for (int i = done + tid; i < n; i += stride)
@@ -254,13 +292,8 @@ namespace
         {
             // three streams in, one out, 16 bytes per lane and access
             const int nv = n / N;
-            for (int i = tid; i < nv; i += stride)
+            auto one = [&](int i, V wv, const V &pv, const V &nvv)
             {
-                V wv = reinterpret_cast<const V *>(w)[i], pv = wv, nvv = wv;
-                if (vprev)
-                    pv = reinterpret_cast<const V *>(vprev)[i];
-                if (vnext)
-                    nvv = reinterpret_cast<const V *>(vnext)[i];
                 T *we = reinterpret_cast<T *>(&wv);
                 const T *pe = reinterpret_cast<const T *>(&pv), *ne = reinterpret_cast<const T *>(&nvv);
 #pragma unroll
@@ -272,6 +305,26 @@ namespace
                 }
                 if (vprev)
                     reinterpret_cast<V *>(w)[i] = wv;
+            };
+            int i = tid;
+            for (; i + stride < nv; i += 2 * stride) // two independent accesses per stream (three streams) in flight
+            {
+                V wv[2], pv[2], nvv[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+                {
+                    wv[u] = reinterpret_cast<const V *>(w)[i + u * stride];
+                    pv[u] = vprev ? reinterpret_cast<const V *>(vprev)[i + u * stride] : wv[u];
+                    nvv[u] = vnext ? reinterpret_cast<const V *>(vnext)[i + u * stride] : wv[u];
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+                    one(i + u * stride, wv[u], pv[u], nvv[u]);
+            }
+            for (; i < nv; i += stride)
+            {
+                const V wv = reinterpret_cast<const V *>(w)[i];
+                one(i, wv, vprev ? reinterpret_cast<const V *>(vprev)[i] : wv, vnext ? reinterpret_cast<const V *>(vnext)[i] : wv);
             }
             done = nv * N;
         }
