@@ -48,12 +48,15 @@ namespace
     // ------------------------------------------------------------ stiffness apply (K1)
     // LDS per workgroup: P, D (nq*nb each) + per element: u (nb*nb), Pu, Du (nq*nb each), F0, F1 (nq*nq each),
     // T0, T1 (nb*nq each)
-    __global__ void __launch_bounds__(BLOCK) stiffness_apply_kernel(int n_elem, int nq, int nb, int E, const double *__restrict__ gP,
+    // NBT, NQT: compile-time n_basis / n_quad (loops unroll, index arithmetic divides by constants); 0 = take the arguments
+    template <int NBT, int NQT>
+    __global__ void __launch_bounds__(BLOCK) stiffness_apply_kernel(int n_elem, int nq_arg, int nb_arg, int E, const double *__restrict__ gP,
                                                                     const double *__restrict__ gD, const double *__restrict__ G,
                                                                     const int *__restrict__ I, double c, const double *__restrict__ x,
                                                                     double *__restrict__ y)
     {
         extern __shared__ double lds[];
+        const int nb = NBT ? NBT : nb_arg, nq = NQT ? NQT : nq_arg;
         const int nbb = nb * nb, nqb = nq * nb, nqq = nq * nq;
         double *P = lds, *D = P + nqb;
         double *u = D + nqb;      // [E][nb*nb]   u(k,l) at k + nb*l
@@ -143,8 +146,8 @@ namespace
 
     // ------------------------------------------------------------ mass set-up (K4) and apply (K3)
     // LDS: P (nq*nb) + per element: u (nb*nb) , A (nq*nb), Q (nq*nq), Bq (nq*nb)
-    template <bool SETUP>
-    __global__ void __launch_bounds__(BLOCK) mass_kernel(int n_elem, int nq, int nb, int E, const double *__restrict__ gP,
+    template <bool SETUP, int NBT, int NQT>
+    __global__ void __launch_bounds__(BLOCK) mass_kernel(int n_elem, int nq_arg, int nb_arg, int E, const double *__restrict__ gP,
                                                          const int *__restrict__ I,
                                                          const double *__restrict__ coef,  // SETUP: nodal coefficient or null
                                                          const double *__restrict__ detJ,  // SETUP
@@ -153,6 +156,7 @@ namespace
                                                          double c, const double *__restrict__ x, double *__restrict__ out)
     {
         extern __shared__ double lds[];
+        const int nb = NBT ? NBT : nb_arg, nq = NQT ? NQT : nq_arg;
         const int nbb = nb * nb, nqb = nq * nb, nqq = nq * nq;
         double *P = lds;
         double *u = P + nqb;      // [E][nb*nb]
@@ -332,8 +336,11 @@ extern "C"
             return static_cast<int>(hipErrorInvalidValue);
         const int E = batch_size(per_elem, shared, nq * nq);
         const size_t lds = (size_t)(shared + E * per_elem) * sizeof(double);
-        hipLaunchKernelGGL(stiffness_apply_kernel, dim3(grid_for_batches(n_elem, E)), dim3(BLOCK), lds, as_stream(stream), n_elem, nq, nb,
-                           E, P, D, G, I, c, x, y);
+        const dim3 grid(grid_for_batches(n_elem, E)), block(BLOCK);
+        hipStream_t st = as_stream(stream);
+        // (compile-time sizes were measured for this kernel too: no gain at n_basis 8, slower at 7 -- it is bound by its LDS
+        // passes and barriers, not by index arithmetic; the mass kernel below does gain)
+        hipLaunchKernelGGL((stiffness_apply_kernel<0, 0>), grid, block, lds, st, n_elem, nq, nb, E, P, D, G, I, c, x, y);
         return launch_status();
     }
 
@@ -348,8 +355,8 @@ extern "C"
             return static_cast<int>(hipErrorInvalidValue);
         const int E = batch_size(per_elem, shared, nq * nq);
         const size_t lds = (size_t)(shared + E * per_elem) * sizeof(double);
-        hipLaunchKernelGGL((mass_kernel<true>), dim3(grid_for_batches(n_elem, E)), dim3(BLOCK), lds, as_stream(stream), n_elem, nq, nb, E, P,
-                           I, coef, detJ, w, static_cast<const double *>(nullptr), 0.0, static_cast<const double *>(nullptr), a);
+        hipLaunchKernelGGL((mass_kernel<true, 0, 0>), dim3(grid_for_batches(n_elem, E)), dim3(BLOCK), lds, as_stream(stream), n_elem, nq, nb, E,
+                           P, I, coef, detJ, w, static_cast<const double *>(nullptr), 0.0, static_cast<const double *>(nullptr), a);
         return launch_status();
     }
 
@@ -364,9 +371,24 @@ extern "C"
             return static_cast<int>(hipErrorInvalidValue);
         const int E = batch_size(per_elem, shared, nq * nq);
         const size_t lds = (size_t)(shared + E * per_elem) * sizeof(double);
-        hipLaunchKernelGGL((mass_kernel<false>), dim3(grid_for_batches(n_elem, E)), dim3(BLOCK), lds, as_stream(stream), n_elem, nq, nb, E,
-                           P, I, static_cast<const double *>(nullptr), static_cast<const double *>(nullptr),
-                           static_cast<const double *>(nullptr), a, c, x, y);
+        const dim3 grid(grid_for_batches(n_elem, E)), block(BLOCK);
+        hipStream_t st = as_stream(stream);
+        const double *none = nullptr;
+#define CUDDH_M_CASE(NB_, NQ_)                                                                                                      \
+    if (nb == NB_ && nq == NQ_)                                                                                                     \
+    {                                                                                                                               \
+        hipLaunchKernelGGL((mass_kernel<false, NB_, NQ_>), grid, block, lds, st, n_elem, nq, nb, E, P, I, none, none, none, a, c, x, y); \
+        return launch_status();                                                                                                     \
+    }
+        // n_basis + 1 (a == 1) and 1 + 3 n_basis / 2 + 1 (weighted), reference source/MassMatrix.cpp:74,108
+        CUDDH_M_CASE(6, 7)
+        CUDDH_M_CASE(7, 8)
+        CUDDH_M_CASE(8, 9)
+        CUDDH_M_CASE(6, 11)
+        CUDDH_M_CASE(7, 12)
+        CUDDH_M_CASE(8, 14)
+#undef CUDDH_M_CASE
+        hipLaunchKernelGGL((mass_kernel<false, 0, 0>), grid, block, lds, st, n_elem, nq, nb, E, P, I, none, none, none, a, c, x, y);
         return launch_status();
     }
 
