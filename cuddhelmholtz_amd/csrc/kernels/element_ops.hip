@@ -20,10 +20,12 @@ namespace
     constexpr int LDS_BUDGET = 48 * 1024; // bytes of dynamic LDS per workgroup (3 workgroups per CU)
 
     // number of elements a workgroup handles at once
-    inline int batch_size(int doubles_per_elem, int shared_doubles, int work_per_elem)
+    // rounds: how many passes of the 256 threads the largest stage should take (measured: 1 is best for the stiffness
+    // kernel, 2 for the mass kernels -- less idle tail per round vs more LDS per workgroup)
+    inline int batch_size(int doubles_per_elem, int shared_doubles, int work_per_elem, int rounds = 1)
     {
         int e = (LDS_BUDGET / 8 - shared_doubles) / doubles_per_elem;
-        const int want = (BLOCK + work_per_elem - 1) / work_per_elem; // enough to occupy every thread
+        const int want = rounds * ((BLOCK + work_per_elem - 1) / work_per_elem);
         if (e > want)
             e = want;
         return e < 1 ? 1 : e;
@@ -369,7 +371,7 @@ extern "C"
         const int shared = nq * nb;
         if ((per_elem + shared) * 8 > 64 * 1024)
             return static_cast<int>(hipErrorInvalidValue);
-        const int E = batch_size(per_elem, shared, nq * nq);
+        const int E = batch_size(per_elem, shared, nq * nq, 2);
         const size_t lds = (size_t)(shared + E * per_elem) * sizeof(double);
         const dim3 grid(grid_for_batches(n_elem, E)), block(BLOCK);
         hipStream_t st = as_stream(stream);
