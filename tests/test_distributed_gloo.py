@@ -200,3 +200,37 @@ def test_neighbour_exchange_reproduces_one_rank(tmp_path, world, overlap):
         assert got["nmv"] == single[3]
         assert torch.allclose(got["lam"], single[1], rtol=1e-10, atol=1e-13 * float(single[1].abs().max()))
         assert torch.allclose(got["u"], single[2], rtol=1e-9, atol=1e-12 * float(single[2].abs().max()))
+
+
+def test_trace_exchange_on_random_slot_tables():
+    """TraceExchange needs nothing but the slot table: random tables (random pairing of face dofs of random subdomains,
+    random orphans and read-only / write-only slots, as the reference's cross-point quirk produces) must still give a
+    partition of the touched slots and mirrored send / receive lists for every world size."""
+    rng = np.random.default_rng(2024)
+    for trial in range(20):
+        n_dom, mx_fdof = int(rng.integers(2, 40)), int(rng.integers(1, 9))
+        n_lambda = int(rng.integers(1, n_dom * mx_fdof + 1))
+        B = -np.ones((mx_fdof, 2, n_dom), dtype=np.int32, order="F")
+        free = [(i, s) for s in range(n_dom) for i in range(mx_fdof)]
+        rng.shuffle(free)
+        for col in (0, 1):  # every slot gets at most one reader and at most one writer, some get none
+            cells = list(free)
+            rng.shuffle(cells)
+            slots = rng.permutation(n_lambda)[: int(rng.integers(0, min(n_lambda, len(cells)) + 1))]
+            for t, (i, s) in zip(slots, cells):
+                B[i, col, s] = t
+        touched = np.unique(B[B >= 0])
+        for world in (1, 2, 3, 7):
+            ex = [TraceExchange(B.ravel(order="F"), n_dom, mx_fdof, n_lambda, r, world) for r in range(world)]
+            owned = np.concatenate([e.owned_slots for e in ex])
+            assert np.array_equal(np.sort(owned), touched)
+            for r in range(world):
+                for s in range(world):
+                    if r != s:
+                        assert np.array_equal(ex[r].send_slots.get(s, np.zeros(0, dtype=np.int64)),
+                                              ex[s].recv_slots.get(r, np.zeros(0, dtype=np.int64)))
+                doms = sorted(d for a, b in ex[r].boundary_ranges + ex[r].interior_ranges for d in range(a, b))
+                assert doms == list(range(ex[r].d0, ex[r].d1))
+                # a slot is sent exactly when its writer is mine and its owner is not
+                sent = np.concatenate(list(ex[r].send_slots.values())) if ex[r].send_slots else np.zeros(0, dtype=np.int64)
+                assert not np.intersect1d(sent, ex[r].owned_slots).size

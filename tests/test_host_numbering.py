@@ -141,3 +141,31 @@ def test_ddh_rejects_bad_block_size():
     fem = cd.H1Space(pm, cd.Basis(4))
     with pytest.raises(RuntimeError):
         cd.DDH(5.0, np.ones(fem.size()), fem, 6, 6)  # 6 is not a multiple of 16 / 4
+
+
+def test_refine_quads_conserves_area_and_conformity(unstructured_square):
+    """cuddhelmholtz_amd.meshtools.refine_quads (host utility, not in the reference): every quad -> 4, counter-clockwise,
+    conforming (the oracle's mesh builder finds exactly two elements per interior edge), same domain area."""
+    from cuddhelmholtz_amd.meshtools import refine_quads
+
+    xy, elems = unstructured_square
+
+    def areas(p, e):
+        q = p[e]
+        x, y = q[..., 0], q[..., 1]
+        return 0.5 * sum(x[:, i] * y[:, (i + 1) % 4] - x[:, (i + 1) % 4] * y[:, i] for i in range(4))
+
+    a0 = areas(xy, elems)
+    for times in (1, 2):
+        x2, e2 = refine_quads(xy, elems, times)
+        assert len(e2) == len(elems) * 4**times
+        a2 = areas(x2, e2)
+        assert a2.min() > 0 and abs(a2.sum() - a0.sum()) < 1e-13
+        # the four children of a straight-sided quad tile it: their areas sum to the parent's
+        assert np.allclose(a2.reshape(len(elems), -1).sum(axis=1), a0, rtol=0, atol=1e-14)
+        m = oracle.Mesh(x2, e2)
+        assert len(m.boundary_edges) == 2**times * 40  # the fixture's boundary has 40 edges
+        n_edges = len(m.edges)
+        assert 4 * len(e2) == 2 * (n_edges - len(m.boundary_edges)) + len(m.boundary_edges)
+        # Euler: V - E + F = 1 for a simply connected planar mesh (outer face not counted)
+        assert len(x2) - n_edges + len(e2) == 1
