@@ -70,6 +70,44 @@ __global__ void __launch_bounds__(64) pk_kernel(float *out, int iters, long long
         cycles[blockIdx.x] = t1 - t0;
 }
 
+// fp64: v_fma_f64 and v_mfma_f64_16x16x4_f64 (eight independent accumulators / four independent 4-register accumulators)
+__global__ void __launch_bounds__(64) fma64_kernel(float *out, int iters, long long *cycles)
+{
+    double a0 = threadIdx.x, a1 = 1, a2 = 2, a3 = 3, a4 = 4, a5 = 5, a6 = 6, a7 = 7, b = 1.0 + 1e-9 * threadIdx.x, c = 1e-12;
+    const long long t0 = clock64();
+    for (int it = 0; it < iters; ++it)
+        asm volatile(REP8("v_fma_f64 %0, %8, %9, %0\n\tv_fma_f64 %1, %8, %9, %1\n\tv_fma_f64 %2, %8, %9, %2\n\tv_fma_f64 %3, %8, %9, %3\n\t"
+                          "v_fma_f64 %4, %8, %9, %4\n\tv_fma_f64 %5, %8, %9, %5\n\tv_fma_f64 %6, %8, %9, %6\n\tv_fma_f64 %7, %8, %9, %7\n\t")
+                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));
+    const long long t1 = clock64();
+    out[blockIdx.x * 64 + threadIdx.x] = static_cast<float>(a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7);
+    if (threadIdx.x == 0)
+        cycles[blockIdx.x] = t1 - t0;
+}
+
+__global__ void __launch_bounds__(64) mfma64_kernel(float *out, int iters, long long *cycles)
+{
+    typedef double d4 __attribute__((ext_vector_type(4)));
+    d4 c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0;
+    const double a = 1.0 + 1e-9 * threadIdx.x, b = 1e-6;
+    const long long t0 = clock64();
+    for (int it = 0; it < iters; ++it)
+    {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) // 64 MFMAs per iteration, like the 64 VALU instructions of the other kernels
+        {
+            c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c1, 0, 0, 0);
+            c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c2, 0, 0, 0);
+            c3 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c3, 0, 0, 0);
+        }
+    }
+    const long long t1 = clock64();
+    out[blockIdx.x * 64 + threadIdx.x] = static_cast<float>(c0.x + c1.y + c2.z + c3.w);
+    if (threadIdx.x == 0)
+        cycles[blockIdx.x] = t1 - t0;
+}
+
 template <typename K>
 void run(const char *name, K kernel, int waves_per_simd)
 {
@@ -114,6 +152,8 @@ int main()
         run("v_fmac_f32_dpp half_mirror", rate_kernel<3>, w);
         run("v_mov_b32_dpp quad_perm", rate_kernel<4>, w);
         run("v_pk_fma_f32", pk_kernel, w);
+        run("v_fma_f64", fma64_kernel, w);
+        run("v_mfma_f64_16x16x4_f64", mfma64_kernel, w);
     }
     return 0;
 }
