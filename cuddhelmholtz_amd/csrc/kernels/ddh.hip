@@ -575,21 +575,25 @@ namespace
     // factors, gx(k,l) = alpha_k beta_l, gz(k,l) = gamma_k delta_l, gy = 0, so the sweep  D^T (G (D u))  collapses to
     //     z(k,l) = beta_l * sum_j Ax(k,j) u(j,l)  +  gamma_k * sum_j Ay(l,j) u(k,j),
     // Ax = D^T diag(alpha) D, Ay = D^T diag(delta) D (8 x 8, built in double when the plan is created): ONE contraction
-    // per direction instead of two.  Sep = [Ax (k + 8 j) | Ay (l + 8 j) | beta | gamma].
+    // per direction instead of two.  Sep = [Ax (k + 8 j): 64 | Ay, packed upper triangle: 36 (+ 28 unused) | beta: 8 | gamma: 8].
+    __host__ __device__ constexpr int sym_index(int a, int b) { return a <= b ? a + b * (b + 1) / 2 : b + a * (a + 1) / 2; }
+
     template <bool ASM, typename Real>
     __device__ inline void wave8_stiffness_sep(const Real (&w)[8], Real (&z)[8], const Real (&AxK)[8], const Real *__restrict__ Sep,
                                                Real gamma, Real mR, Real mL, Real mU, Real mD, int lane)
     {
+        // Ay is symmetric: its 36 distinct entries are stored packed (upper triangle, column by column) so that they and
+        // beta can stay in scalar registers for the whole time loop
         const Real *Ay = Sep + 64, *beta = Sep + 128;
         Real X[8], zz[8];
         octet_contract_any<ASM>(w, AxK, X);
 #pragma unroll
         for (int l = 0; l < 8; ++l)
         {
-            Real s = Ay[l] * w[0];
+            Real s = Ay[sym_index(l, 0)] * w[0];
 #pragma unroll
             for (int j = 1; j < 8; ++j)
-                s += Ay[l + 8 * j] * w[j];
+                s += Ay[sym_index(l, j)] * w[j];
             zz[l] = gamma * s + beta[l] * X[l];
         }
         if constexpr (ASM && sizeof(Real) == 4)
@@ -1356,7 +1360,7 @@ namespace
                 if (std::fabs(g(1, k, l)) > 1e-6 * scale || std::fabs(g(0, k, l) - alpha[k] * beta[l]) > 1e-6 * scale ||
                     std::fabs(g(2, k, l) - gamma[k] * delta[l]) > 1e-6 * scale)
                     return -1;
-        float hS[144];
+        float hS[144] = {0};
         for (int a = 0; a < 8; ++a)
             for (int b = 0; b < 8; ++b)
             {
@@ -1367,7 +1371,8 @@ namespace
                     ay += Dm(i, a) * delta[i] * Dm(i, b);
                 }
                 hS[a + 8 * b] = static_cast<float>(ax);
-                hS[64 + a + 8 * b] = static_cast<float>(ay);
+                if (a <= b)
+                    hS[64 + sym_index(a, b)] = static_cast<float>(ay); // Ay(a,b) == Ay(b,a)
             }
         for (int i = 0; i < 8; ++i)
         {
