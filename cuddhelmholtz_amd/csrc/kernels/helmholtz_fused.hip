@@ -36,7 +36,7 @@ struct cuddh_helmholtz_plan
     // per patch
     int *dof_off = nullptr;   // [n_patches + 1] offsets into dof_list / slot_of
     int *dof_list = nullptr;  // global dof of every patch-local dof
-    int *slot_of = nullptr;   // -1: the patch owns the dof, else its slot in `part`
+    int *slot_of = nullptr;   // where a patch-local dof's result goes: its global dof (>= 0) if the patch owns it, else -(slot in `part`) - 1
     int *patch_nel = nullptr; // elements in the patch (32 except possibly the last)
     uint32_t *lidx = nullptr; // [n_patches][ceil(nb*nb/2)][32]: element nodes 2j, 2j+1 -> patch-local dofs, packed lo | hi << 16
     uint8_t *colour = nullptr; // [n_patches][32]
@@ -389,29 +389,26 @@ namespace
         const int *slot = A.slot_of + off;
         for (int base = 0; base < nloc; base += 64 * ROWS)
         {
-            int si[ROWS], gi[ROWS];
+            int dest[ROWS]; // one index per dof: global dof (owned) or -(slot) - 1 (border)
 #pragma unroll
             for (int j = 0; j < ROWS; ++j)
-            {
-                const int i = min(base + 64 * j + lane, nloc - 1);
-                si[j] = slot[i];
-                gi[j] = dofs[i];
-            }
+                dest[j] = slot[min(base + 64 * j + lane, nloc - 1)];
 #pragma unroll
             for (int j = 0; j < ROWS; ++j)
             {
                 const int i = base + 64 * j + lane;
                 if (i >= nloc)
                     continue;
-                if (si[j] < 0)
+                if (dest[j] >= 0)
                 {
-                    A.y[gi[j]] = ys[i];
-                    A.y[A.ndof + gi[j]] = ys[ML + i];
+                    A.y[dest[j]] = ys[i];
+                    A.y[A.ndof + dest[j]] = ys[ML + i];
                 }
                 else
                 {
-                    A.part[si[j]] = ys[i];
-                    A.part[A.n_slots + si[j]] = ys[ML + i];
+                    const int sl = -dest[j] - 1;
+                    A.part[sl] = ys[i];
+                    A.part[A.n_slots + sl] = ys[ML + i];
                 }
             }
         }
@@ -776,18 +773,14 @@ namespace
         const int *slot = A.slot_of + off;
         for (int base = 0; base < ntot; base += 64 * ROWS)
         {
-            int si[ROWS], gi[ROWS];
+            int dest[ROWS]; // one index per dof: global dof (owned) or -(slot) - 1 (border)
             double y0[ROWS];
 #pragma unroll
             for (int j = 0; j < ROWS; ++j)
-            {
-                const int t = min(base + 64 * j + lane, ntot - 1);
-                si[j] = slot[t];
-                gi[j] = dofs[t];
-            }
+                dest[j] = slot[min(base + 64 * j + lane, ntot - 1)];
 #pragma unroll
             for (int j = 0; j < ROWS; ++j)
-                y0[j] = (accumulate && si[j] < 0) ? A.y[gi[j]] : 0.0;
+                y0[j] = (accumulate && dest[j] >= 0) ? A.y[dest[j]] : 0.0;
 #pragma unroll
             for (int j = 0; j < ROWS; ++j)
             {
@@ -795,10 +788,10 @@ namespace
                 if (t >= ntot)
                     continue;
                 const double val = c * ys[t < n0 ? t : ML + (t - n0)];
-                if (si[j] < 0)
-                    A.y[gi[j]] = y0[j] + val;
+                if (dest[j] >= 0)
+                    A.y[dest[j]] = y0[j] + val;
                 else
-                    A.part[si[j]] = val;
+                    A.part[-dest[j] - 1] = val;
             }
         }
     }
@@ -1043,15 +1036,12 @@ extern "C"
             }
         const int n_shared = static_cast<int>(shared_dof.size());
         const int n_slots = shared_off.back();
-        std::vector<int> slot_of(dof_list.size(), -1), fill(shared_off.begin(), shared_off.end() - 1);
+        std::vector<int> slot_of(dof_list.size()), fill(shared_off.begin(), shared_off.end() - 1);
         for (size_t i = 0; i < dof_list.size(); ++i)
         {
             const int j = shared_index[dof_list[i]];
-            if (j >= 0)
-            {
-                const int s = fill[j]++;
-                slot_of[i] = s;        // slots of one dof are contiguous and ordered by patch
-            }
+            // owned: the global dof itself; border: -(slot) - 1, the slots of one dof being contiguous and ordered by patch
+            slot_of[i] = j >= 0 ? -(fill[j]++) - 1 : dof_list[i];
         }
         p->n_shared = n_shared;
         p->n_slots = n_slots;
@@ -1125,8 +1115,9 @@ extern "C"
                        (size_t)ndof * (single ? 16 : 32) + (size_t)n_faces * ((size_t)nqF * 8 + (size_t)nb * 4);
         size_t exclusive = 0;
         for (int s : slot_of)
-            exclusive += s < 0;
-        p->bytes_actual = (size_t)nG * 8 + (size_t)nA * 8 + lidx.size() * 4 + colour.size() + dof_list.size() * (4 + 4 + 16) +
+            exclusive += s >= 0;
+        p->bytes_actual = (size_t)nG * 8 + (size_t)nA * 8 + lidx.size() * 4 + colour.size() + dof_list.size() * (4 + 4 + 16) + // dof (gather), destination (write-out), x
+                         
                           exclusive * 16 + (size_t)n_slots * (16 + 16) + (size_t)n_shared * (16 + 8) +
                           (size_t)n_faces * ((size_t)nqF * 8 + (size_t)nb * 2 + 5);
         if (p->Gu || p->au) // SURVEY 8d's "affine" figure: the uniform metric arrays are not traffic
