@@ -658,3 +658,37 @@ def test_fused_apply_on_refined_unstructured_mesh(cuda):
     yS = torch.empty(d.ndof, dtype=torch.float64, device=cuda)
     cd.StiffnessMatrix(fem).action(x[: d.ndof], yS)
     assert rel(yS.cpu().numpy(), oracle.Stiffness(d).apply(xh[: d.ndof])) < 1e-12
+
+
+@pytest.mark.parametrize("nx,nb", [(1, 2), (1, 4), (2, 3), (3, 5), (6, 4), (7, 6)])
+def test_operators_on_tiny_meshes(cuda, nx, nb):
+    """Edge cases of the patch plans: a single element, a single (partly filled) patch, no border dofs at all, an odd
+    number of patches (the real-operator kernels take patches in pairs), n_basis 6 (fused plan + generic single operators)."""
+    import torch
+
+    import cuddhelmholtz_amd as cd
+
+    pm, om = meshes("structured", nx)
+    fem = cd.H1Space(pm, cd.Basis(nb))
+    d = oracle.Discretization(om, nb)
+    faces = pm.boundary_edges()
+    fs = cd.FaceSpace(fem, faces)
+    ofs = oracle.FaceSpaceO(d, list(faces))
+    rng = np.random.default_rng(1000 * nx + nb)
+    a2, ax = 0.5 + rng.random(d.ndof), 0.5 + rng.random(ofs.size)
+    xh = rng.standard_normal(2 * d.ndof)
+    x = to_dev(torch, xh, cuda)
+    omega = 3.0
+    A = cd.HelmholtzOperator(omega, to_dev(torch, a2, cuda), to_dev(torch, ax, cuda), fem, fs)
+    assert A.fused()
+    y = torch.full((2 * d.ndof,), -1.0, dtype=torch.float64, device=cuda)
+    A.action(x, y)
+    ref = oracle.helmholtz_apply(d, oracle.Stiffness(d), oracle.Mass(d, a2), oracle.FaceMass(ofs, ax), ofs, omega, xh)
+    assert rel(y.cpu().numpy(), ref) < 1e-12
+    yS = torch.full((d.ndof,), 2.0, dtype=torch.float64, device=cuda)
+    S, M = cd.StiffnessMatrix(fem), cd.MassMatrix(fem, to_dev(torch, a2, cuda))
+    S.action(x[: d.ndof], yS)
+    refS = oracle.Stiffness(d).apply(xh[: d.ndof])
+    assert rel(yS.cpu().numpy(), refS) < 1e-12
+    M.action(-2.0, x[: d.ndof], yS)
+    assert rel(yS.cpu().numpy(), refS - 2.0 * oracle.Mass(d, a2).apply(xh[: d.ndof])) < 1e-12
