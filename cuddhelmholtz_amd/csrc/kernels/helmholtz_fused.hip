@@ -147,6 +147,17 @@ namespace
         }
 
         constexpr int ROWS = 6; // 64-lane rows per pass: 384 dofs cover a 4x8-element patch of n_basis 4 (325) in one pass
+        // where the results of the first pass of the write-out go: requested here, with everything else that is independent
+        // of the element phase, when the registers allow (EARLY), otherwise just before the colour phases
+        constexpr bool EARLY = !UG && NB == 4;
+        const int *slot = A.slot_of + off;
+        int dest0[ROWS];
+        if constexpr (EARLY)
+        {
+#pragma unroll
+            for (int j = 0; j < ROWS; ++j)
+                dest0[j] = slot[min(64 * j + lane, nloc - 1)];
+        }
         for (int base = 0; base < nloc; base += 64 * ROWS)
         {
             int gi[ROWS];
@@ -313,6 +324,13 @@ namespace
             }
         }
 
+        if constexpr (!EARLY)
+        {
+#pragma unroll
+            for (int j = 0; j < ROWS; ++j)
+                dest0[j] = slot[min(64 * j + lane, nloc - 1)];
+        }
+
         // accumulate: elements of one colour touch disjoint dofs
         {
             const double sgn = comp ? -1.0 : 1.0; // the v row is negated (symmetrised system)
@@ -386,13 +404,12 @@ namespace
         }
 
         // ------------------------------------------------------------ write out
-        const int *slot = A.slot_of + off;
         for (int base = 0; base < nloc; base += 64 * ROWS)
         {
             int dest[ROWS]; // one index per dof: global dof (owned) or -(slot) - 1 (border)
 #pragma unroll
             for (int j = 0; j < ROWS; ++j)
-                dest[j] = slot[min(base + 64 * j + lane, nloc - 1)];
+                dest[j] = base == 0 ? dest0[j] : slot[min(base + 64 * j + lane, nloc - 1)];
 #pragma unroll
             for (int j = 0; j < ROWS; ++j)
             {
@@ -629,6 +646,15 @@ namespace
             load_slice(0, g_first);
 
         constexpr int ROWS = 12; // 768 dofs per pass: both patches of n_basis 4 (2 x 325) in one
+        constexpr bool EARLY = false; // measured: holding them across the element phase costs this kernel more than the round trip
+        const int *slot = A.slot_of + off;
+        int dest0[ROWS];
+        if constexpr (EARLY)
+        {
+#pragma unroll
+            for (int j = 0; j < ROWS; ++j)
+                dest0[j] = slot[min(64 * j + lane, ntot - 1)];
+        }
         for (int base = 0; base < ntot; base += 64 * ROWS)
         {
             int gi[ROWS];
@@ -753,6 +779,13 @@ namespace
             slice(q, g);
         }
 
+        if constexpr (!EARLY)
+        {
+#pragma unroll
+            for (int j = 0; j < ROWS; ++j)
+                dest0[j] = slot[min(64 * j + lane, ntot - 1)];
+        }
+
         // accumulate in colour phases (both patches at once: they use different halves of ys)
         {
             double *yc = ys + half * ML;
@@ -770,14 +803,13 @@ namespace
 
         // ------------------------------------------------------------ write out
         const double c = A.omega; // the scale factor travels in the omega field
-        const int *slot = A.slot_of + off;
         for (int base = 0; base < ntot; base += 64 * ROWS)
         {
             int dest[ROWS]; // one index per dof: global dof (owned) or -(slot) - 1 (border)
             double y0[ROWS];
 #pragma unroll
             for (int j = 0; j < ROWS; ++j)
-                dest[j] = slot[min(base + 64 * j + lane, ntot - 1)];
+                dest[j] = base == 0 ? dest0[j] : slot[min(base + 64 * j + lane, ntot - 1)];
 #pragma unroll
             for (int j = 0; j < ROWS; ++j)
                 y0[j] = (accumulate && dest[j] >= 0) ? A.y[dest[j]] : 0.0;
