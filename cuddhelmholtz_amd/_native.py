@@ -146,6 +146,8 @@ for _n in ("n_elem", "n_edges", "n_nodes", "n_boundary_edges"):
     _sig(f"cuddh_mesh_{_n}", ci, vp)
 _sig("cuddh_mesh_boundary_edges", ci, vp, vp)
 _sig("cuddh_mesh_edges", ci, vp, vp)
+_sig("cuddh_mesh_vertices", ci, vp, vp)
+_sig("cuddh_mesh_elements", ci, vp, vp)
 _sig("cuddh_mesh_min_h", cd, vp)
 _sig("cuddh_h1space_create", vp, vp, vp)
 _sig("cuddh_h1space_destroy", None, vp)

@@ -120,6 +120,18 @@ class Mesh2D:
         N.check_capi(lib.cuddh_mesh_boundary_edges(self._h, _h(out)))
         return out
 
+    def vertices(self) -> np.ndarray:
+        """(n_nodes, 2) vertex coordinates"""
+        out = np.empty((self.n_nodes(), 2))
+        N.check_capi(lib.cuddh_mesh_vertices(self._h, _h(out)))
+        return out
+
+    def elements(self) -> np.ndarray:
+        """(n_elem, 4) corner vertex ids, counter-clockwise"""
+        out = np.empty((self.n_elem(), 4), dtype=np.int32)
+        N.check_capi(lib.cuddh_mesh_elements(self._h, _h(out)))
+        return out
+
     def edges(self) -> np.ndarray:
         """(n_edges, 8): type(1=boundary), node0, node1, elem0, elem1, side0, side1, delta"""
         out = np.empty((self.n_edges(), 8), dtype=np.int32)

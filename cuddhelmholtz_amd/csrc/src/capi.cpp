@@ -241,6 +241,28 @@ extern "C"
         });
     }
     double cuddh_mesh_min_h(void *m) { return static_cast<Mesh2D *>(m)->min_h(); }
+    int cuddh_mesh_vertices(void *m, double *h_xy)
+    {
+        return guarded([&]
+        {
+            const Mesh2D *mesh = static_cast<Mesh2D *>(m);
+            for (int i = 0; i < mesh->n_nodes(); ++i)
+            {
+                h_xy[2 * i] = mesh->node(i).x[0];
+                h_xy[2 * i + 1] = mesh->node(i).x[1];
+            }
+        });
+    }
+    int cuddh_mesh_elements(void *m, int *h_out)
+    {
+        return guarded([&]
+        {
+            const Mesh2D *mesh = static_cast<Mesh2D *>(m);
+            for (int e = 0; e < mesh->n_elem(); ++e)
+                for (int c = 0; c < 4; ++c)
+                    h_out[4 * e + c] = mesh->element(e)->nodes[c];
+        });
+    }
 
     // ------------------------------------------------------------ spaces
     void *cuddh_h1space_create(void *mesh, void *basis)

@@ -272,3 +272,222 @@ class NeighbourShardedDDH:
         if gmres is None:
             from .api import gmres
         return gmres(lam.numel(), lam, self.action, b, m, maxit, tol, reduce=self.reduce, **kw)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Global operator apply over several GPUs ("next"): element partition + halo exchange of shared dofs
+# ---------------------------------------------------------------------------------------------------------------------
+def _morton_keys(xy):
+    import numpy as np
+
+    lo, hi = xy.min(axis=0), xy.max(axis=0)
+    span = np.where(hi > lo, hi - lo, 1.0)
+    c = np.clip(((xy - lo) / span * 65535.0 + 0.5).astype(np.uint64), 0, 65535)
+
+    def spread(v):
+        v = v & np.uint64(0xFFFF)
+        for shift, mask in ((8, 0x00FF00FF), (4, 0x0F0F0F0F), (2, 0x33333333), (1, 0x55555555)):
+            v = (v | (v << np.uint64(shift))) & np.uint64(mask)
+        return v
+
+    return spread(c[:, 0]) | (spread(c[:, 1]) << np.uint64(1))
+
+
+class HelmholtzPartition:
+    """Host-side description of one rank's share of the fused Helmholtz operator.
+
+    Elements are split into `world` contiguous ranges of the Morton order of their centroids (compact regions).  A rank
+    builds an ordinary mesh / H1Space / FaceSpace of its own elements (so the local numbering is the reference's rule on
+    the sub-mesh and every existing kernel applies unchanged); `l2g` maps its dofs to the global ones.  A dof touched by
+    elements of several ranks is OWNED by the lowest of them; the others hold it as halo.  Vectors are stored per rank in
+    local numbering, [u_loc; v_loc], and are ZERO at halo entries, so inner products are the sum of the local ones.
+
+    Before an apply the owners send x at the dofs other ranks hold as halo; after it the halo holders send their partial
+    sums of y back to the owners and clear them.  Both exchanges list dofs in increasing global id on both sides."""
+
+    def __init__(self, cd, mesh, fem, fs, rank: int, world: int):
+        import numpy as np
+
+        self.rank, self.world = rank, world
+        nb = fem.basis.n
+        I = fem.global_indices()  # (nb, nb, n_elem), reference layout
+        n_elem, ndof = mesh.n_elem(), fem.size()
+        xy, elems = mesh.vertices(), mesh.elements().astype(np.int64)
+        order = np.argsort(_morton_keys(xy[elems].mean(axis=1)), kind="stable")
+        elem_rank = np.empty(n_elem, dtype=np.int64)
+        for r in range(world):
+            a, b = partition(n_elem, r, world)
+            elem_rank[order[a:b]] = r
+        self.my_elems = np.flatnonzero(elem_rank == rank)
+        if self.my_elems.size == 0:
+            raise ValueError("HelmholtzPartition: more ranks than elements")
+        If = I.reshape(nb * nb, n_elem, order="F")  # column e = dofs of element e
+        owner = np.full(ndof, world, dtype=np.int64)
+        np.minimum.at(owner, If.ravel(order="F"), np.repeat(elem_rank, nb * nb))
+        self.ndof_global = ndof
+
+        # ---- the sub-mesh and its spaces
+        verts = np.unique(elems[self.my_elems])
+        remap = np.full(len(xy), -1, dtype=np.int64)
+        remap[verts] = np.arange(len(verts))
+        self.mesh = cd.Mesh2D.from_vertices(xy[verts], remap[elems[self.my_elems]])
+        self.fem = cd.H1Space(self.mesh, cd.Basis(nb))
+        n_loc = self.fem.size()
+        I_loc = self.fem.global_indices().reshape(nb * nb, len(self.my_elems), order="F")
+        l2g = np.full(n_loc, -1, dtype=np.int64)
+        l2g[I_loc.ravel(order="F")] = If[:, self.my_elems].ravel(order="F")
+        if (l2g < 0).any() or not np.array_equal(l2g[I_loc], If[:, self.my_elems]) or np.unique(l2g).size != n_loc:
+            raise RuntimeError("HelmholtzPartition: local and global numberings are inconsistent")
+        self.l2g, self.n_loc = l2g, n_loc
+
+        # ---- physical boundary faces of the sub-mesh (its other boundary edges are cuts between ranks)
+        ge, le = mesh.edges(), self.mesh.edges()
+        nv = len(xy)
+        gb = ge[:, 0] == 1
+        gkey_b = (np.minimum(ge[gb, 1], ge[gb, 2]).astype(np.int64) * nv + np.maximum(ge[gb, 1], ge[gb, 2]))
+        lb = np.flatnonzero(le[:, 0] == 1)
+        v0, v1 = verts[le[lb, 1]], verts[le[lb, 2]]
+        lkey = np.minimum(v0, v1) * nv + np.maximum(v0, v1)
+        self.faces = lb[np.isin(lkey, gkey_b)].astype(np.int32)
+        self.fs = cd.FaceSpace(self.fem, self.faces)
+        # face-space coefficient map: local face dof -> global face dof
+        g2f = np.full(ndof, -1, dtype=np.int64)
+        g2f[fs.global_indices()] = np.arange(fs.size())
+        self.face_l2g = g2f[l2g[self.fs.global_indices()]] if self.fs.size() else np.zeros(0, dtype=np.int64)
+        if (self.face_l2g < 0).any():
+            raise RuntimeError("HelmholtzPartition: a local boundary-face dof is not in the global FaceSpace")
+
+        # ---- ownership and the two exchanges
+        own_of_local = owner[l2g]
+        self.owned = np.flatnonzero(own_of_local == rank)
+        self.halo = np.flatnonzero(own_of_local != rank)
+        held_by = {}  # which of MY owned dofs other ranks hold
+        for s in range(world):
+            if s == rank:
+                continue
+            dofs_s = np.unique(If[:, elem_rank == s])
+            mine = dofs_s[owner[dofs_s] == rank]  # sorted by global id
+            if mine.size:
+                held_by[s] = mine
+        g2l = np.full(ndof, -1, dtype=np.int64)
+        g2l[l2g] = np.arange(n_loc)
+        # owners -> halo holders (x), halo holders -> owners (partial y): local ids, ordered by global id on both sides
+        self.own_to = {s: g2l[g] for s, g in held_by.items()}
+        self.halo_from = {}
+        for s in range(world):
+            if s == rank:
+                continue
+            h = self.halo[own_of_local[self.halo] == s]
+            if h.size:
+                self.halo_from[s] = h[np.argsort(l2g[h], kind="stable")]
+
+    def both_components(self, ids):
+        """entries of a local [u_loc; v_loc] vector for a set of local dofs"""
+        import numpy as np
+
+        return np.concatenate([ids, ids + self.n_loc])
+
+
+class ShardedHelmholtz:
+    """The fused complex Helmholtz operator (examples/Helmholtz.hpp:28-56) over `world` ranks, vectors partitioned by dof
+    ownership (HelmholtzPartition).  `action(x, y)` works on local vectors of length 2 * n_loc that are zero at halo
+    entries; `reduce` sums inner products over the ranks (pass it to cuddhelmholtz_amd.gmres(..., reduce=))."""
+
+    def __init__(self, cd, omega, a2x, ax, mesh, fem, fs, rank: int = 0, world: int = 1, group=None, device="cuda",
+                 host_staging: bool = False):
+        import numpy as np
+        import torch
+
+        self.rank, self.world, self.group, self.host_staging = rank, world, group, host_staging
+        self.device = torch.device(device)
+        self.part = p = HelmholtzPartition(cd, mesh, fem, fs, rank, world)
+        a2x, ax = np.asarray(a2x, dtype=np.float64), np.asarray(ax, dtype=np.float64)
+        dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(self.device)  # noqa: E731
+        self.op = cd.HelmholtzOperator(omega, dev(a2x[p.l2g]), dev(ax[p.face_l2g]), p.fem, p.fs)
+        self.n_loc = p.n_loc
+        idx = lambda ids: torch.from_numpy(p.both_components(ids)).to(self.device)  # noqa: E731
+        self.own_to = {s: idx(v) for s, v in p.own_to.items()}
+        self.halo_from = {s: idx(v) for s, v in p.halo_from.items()}
+        self.halo_idx = idx(p.halo)
+        self.owned_idx = idx(p.owned)
+        self._scratch = torch.zeros(2 * p.n_loc, dtype=torch.float64, device=self.device)
+
+    # ---- the two exchanges, as pack / unpack pairs (an in-process replay of several ranks calls them directly)
+    def pack_x(self, x):
+        return {s: x.index_select(0, idx) for s, idx in self.own_to.items()}
+
+    def unpack_x(self, x, received) -> None:
+        for s, idx in self.halo_from.items():
+            x.index_copy_(0, idx, received[s].to(x.device))
+
+    def pack_y(self, y):
+        return {s: y.index_select(0, idx) for s, idx in self.halo_from.items()}
+
+    def unpack_y(self, y, received) -> None:
+        for s, idx in self.own_to.items():
+            y.index_add_(0, idx, received[s].to(y.device))
+        y.index_fill_(0, self.halo_idx, 0.0)
+
+    def _exchange(self, outgoing, incoming_sizes):
+        import torch
+        import torch.distributed as dist
+
+        stage = (lambda t: t.cpu()) if self.host_staging else (lambda t: t)  # noqa: E731
+        sbuf = {s: stage(t.contiguous()) for s, t in outgoing.items()}
+        rbuf = {s: torch.empty(n, dtype=torch.float64, device="cpu" if self.host_staging else self.device) for s, n in incoming_sizes.items()}
+        ops = []
+        for s in sorted(set(sbuf) | set(rbuf)):
+            if s in sbuf:
+                ops.append(dist.P2POp(dist.isend, sbuf[s], s, self.group))
+            if s in rbuf:
+                ops.append(dist.P2POp(dist.irecv, rbuf[s], s, self.group))
+        for r in (dist.batch_isend_irecv(ops) if ops else []):
+            r.wait()
+        return rbuf
+
+    def action(self, x, y) -> None:
+        """y = A x on the owned entries (halo entries of x are ignored and fetched from their owners; those of y end zero)"""
+        xs = self._scratch
+        xs.copy_(x)
+        if self.world > 1:
+            self.unpack_x(xs, self._exchange(self.pack_x(xs), {s: i.numel() for s, i in self.halo_from.items()}))
+        self.op.action(xs, y)
+        if self.world > 1:
+            self.unpack_y(y, self._exchange(self.pack_y(y), {s: i.numel() for s, i in self.own_to.items()}))
+
+    def reduce(self, t) -> None:
+        if self.world > 1:
+            import torch.distributed as dist
+
+            if self.host_staging and t.device.type != "cpu":
+                h = t.cpu()
+                dist.all_reduce(h, group=self.group)
+                t.copy_(h)
+            else:
+                dist.all_reduce(t, group=self.group)
+
+    # ---- moving between the global numbering (on every rank) and this rank's partitioned vector
+    def scatter(self, v_global):
+        """global [u; v] (2 * ndof) -> local vector, zero at halo entries"""
+        import torch
+
+        p = self.part
+        g = torch.from_numpy(p.l2g).to(v_global.device)
+        nd = p.ndof_global
+        z = torch.cat([v_global[:nd].index_select(0, g), v_global[nd:].index_select(0, g)]).to(self.device)
+        z.index_fill_(0, self.halo_idx, 0.0)
+        return z
+
+    def gather(self, z):
+        """local vector -> global [u; v] on every rank (sum over the ranks of the owned entries)"""
+        import torch
+
+        p = self.part
+        nd = p.ndof_global
+        out = torch.zeros(2 * nd, dtype=torch.float64, device=self.device)
+        own = torch.from_numpy(p.owned).to(self.device)
+        g = torch.from_numpy(p.l2g[p.owned]).to(self.device)
+        out.index_copy_(0, g, z.index_select(0, own))
+        out.index_copy_(0, g + nd, z.index_select(0, own + p.n_loc))
+        self.reduce(out)
+        return out

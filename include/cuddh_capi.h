@@ -41,6 +41,8 @@ int cuddh_mesh_boundary_edges(void *mesh, int *h_out);
 /* h_out[8*e..] = {type (0 interior, 1 boundary), node0, node1, elem0, elem1, side0, side1, delta} for every edge */
 int cuddh_mesh_edges(void *mesh, int *h_out);
 double cuddh_mesh_min_h(void *mesh);
+int cuddh_mesh_vertices(void *mesh, double *h_xy);  /* (n_nodes, 2) */
+int cuddh_mesh_elements(void *mesh, int *h_elems);  /* (n_elem, 4) corner node ids, counter-clockwise */
 
 /* ---- spaces (reference include/H1Space.hpp) */
 void *cuddh_h1space_create(void *mesh, void *basis);

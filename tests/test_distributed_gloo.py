@@ -234,3 +234,77 @@ def test_trace_exchange_on_random_slot_tables():
                 # a slot is sent exactly when its writer is mine and its owner is not
                 sent = np.concatenate(list(ex[r].send_slots.values())) if ex[r].send_slots else np.zeros(0, dtype=np.int64)
                 assert not np.intersect1d(sent, ex[r].owned_slots).size
+
+
+# ------------------------------------------------------------------ partitioned global Helmholtz operator (host logic)
+@pytest.mark.parametrize("kind,nb", [("structured", 3), ("structured", 4), ("unstructured", 3)])
+def test_helmholtz_partition_replay(kind, nb, unstructured_square):
+    """HelmholtzPartition (element partition, local sub-mesh numbering, ownership, the two halo exchanges) replayed in one
+    process for 1..5 ranks with the oracle as the local operator: the assembled result must be the oracle's global apply."""
+    import cuddhelmholtz_amd as cd
+    from cuddhelmholtz_amd.dist import HelmholtzPartition
+
+    if kind == "structured":
+        nx = 7
+        pm, om = cd.Mesh2D.uniform_rect(nx, -1.0, 1.0, nx, -1.0, 1.0), oracle.Mesh.uniform_rect(nx, -1.0, 1.0, nx, -1.0, 1.0)
+    else:
+        xy, elems = unstructured_square
+        pm, om = cd.Mesh2D.from_vertices(xy, elems), oracle.Mesh(xy, elems)
+    fem = cd.H1Space(pm, cd.Basis(nb))
+    faces = pm.boundary_edges()
+    fs = cd.FaceSpace(fem, faces)
+    d = oracle.Discretization(om, nb)
+    ofs = oracle.FaceSpaceO(d, list(faces))
+    ndof = d.ndof
+    rng = np.random.default_rng(5)
+    a2, ax = 0.5 + rng.random(ndof), 0.5 + rng.random(ofs.size)
+    xg = rng.standard_normal(2 * ndof)
+    omega = 4.0
+    ref = oracle.helmholtz_apply(d, oracle.Stiffness(d), oracle.Mass(d, a2), oracle.FaceMass(ofs, ax), ofs, omega, xg)
+
+    for world in (1, 2, 3, 5):
+        parts = [HelmholtzPartition(cd, pm, fem, fs, r, world) for r in range(world)]
+        # ownership is a partition of the dofs; every element belongs to exactly one rank
+        owned_g = np.concatenate([p.l2g[p.owned] for p in parts])
+        assert np.array_equal(np.sort(owned_g), np.arange(ndof))
+        assert np.array_equal(np.sort(np.concatenate([p.my_elems for p in parts])), np.arange(pm.n_elem()))
+        assert sum(len(p.faces) for p in parts) == len(faces)
+        # local operators (oracle) on the sub-meshes, in the product's local numbering
+        local = []
+        for p in parts:
+            lm = oracle.Mesh(p.mesh.vertices(), p.mesh.elements())
+            ld = oracle.Discretization(lm, nb)
+            assert np.array_equal(ld.I, p.fem.global_indices())
+            lofs = oracle.FaceSpaceO(ld, list(p.faces))
+            assert np.array_equal(lofs.proj, p.fs.global_indices())
+            local.append((ld, lofs, a2[p.l2g], ax[p.face_l2g]))
+        # partitioned vectors: zero at halo entries
+        xs = []
+        for p in parts:
+            z = np.concatenate([xg[:ndof][p.l2g], xg[ndof:][p.l2g]])
+            z[p.both_components(p.halo)] = 0.0
+            xs.append(z)
+        # exchange 1: owners -> halo holders
+        for p in parts:
+            for s, ids in p.own_to.items():
+                dst = parts[s].halo_from[p.rank]
+                assert np.array_equal(p.l2g[ids], parts[s].l2g[dst])  # same dofs, same order, on both sides
+                xs[s][parts[s].both_components(dst)] = xs[p.rank][p.both_components(ids)]
+        ys = []
+        for p, (ld, lofs, a2l, axl), z in zip(parts, local, xs):
+            assert np.allclose(z[: p.n_loc], xg[:ndof][p.l2g]) and np.allclose(z[p.n_loc:], xg[ndof:][p.l2g])
+            ys.append(oracle.helmholtz_apply(ld, oracle.Stiffness(ld), oracle.Mass(ld, a2l), oracle.FaceMass(lofs, axl), lofs, omega, z))
+        # exchange 2: halo holders -> owners (partial sums), halo cleared
+        incoming = [dict() for _ in parts]
+        for p in parts:
+            for s, ids in p.halo_from.items():
+                incoming[s][p.rank] = ys[p.rank][p.both_components(ids)]
+        for p in parts:
+            for s, ids in p.own_to.items():
+                ys[p.rank][p.both_components(ids)] += incoming[p.rank][s]
+            ys[p.rank][p.both_components(p.halo)] = 0.0
+        out = np.zeros(2 * ndof)
+        for p, y in zip(parts, ys):
+            out[p.l2g[p.owned]] = y[p.owned]
+            out[ndof + p.l2g[p.owned]] = y[p.n_loc + p.owned]
+        assert np.linalg.norm(out - ref) <= 1e-13 * np.linalg.norm(ref)
