@@ -67,6 +67,9 @@ def main() -> None:
     ap.add_argument("--rehearse-gloo", action="store_true",
                     help="rehearsal of the N > 1 host logic on ONE GPU: all ranks share cuda:0, process group on gloo with host-staged "
                          "payloads (RCCL needs one GPU per rank).  Not a measurement.")
+    ap.add_argument("--sharded-apply", action="store_true",
+                    help="N > 1: also time the partitioned global Helmholtz apply (element partition + halo exchanges, "
+                         "cuddhelmholtz_amd.dist.ShardedHelmholtz) and report its aggregate rate as `roofline_sharded`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -281,6 +284,15 @@ def main() -> None:
     if rank == 0 and not args.no_roofline:
         result["roofline"] = helmholtz_roofline(cd, torch, dev, fem, mesh, omega, ndof)
 
+    # ---------------------------------------------------------------- optional: the partitioned global apply over the N ranks
+    if world > 1 and args.sharded_apply:
+        try:
+            result_sh = sharded_apply_rate(cd, torch, dist, dev, fem, mesh, omega, ndof, rank, world, staged, allred)
+        except Exception as e:  # noqa: BLE001
+            result_sh = {"error": f"{type(e).__name__}: {e}"}
+        if rank == 0:
+            result["roofline_sharded"] = result_sh
+
     # ---------------------------------------------------------------- CPU baseline (oracle), N = 1 only
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(F, info, ndof, nb, omega, args.cpu_seconds)
@@ -290,6 +302,44 @@ def main() -> None:
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(result), flush=True)
+
+
+def sharded_apply_rate(cd, torch, dist, dev, fem, mesh, omega, ndof, rank, world, staged, allred):
+    """Aggregate algorithmic GB/s of the fused Helmholtz apply partitioned over the ranks (general-geometry layout, a = 1):
+    SURVEY 8d bytes of the whole mesh / MAX over ranks of the time per apply, halo exchanges included."""
+    from cuddhelmholtz_amd.dist import ShardedHelmholtz
+
+    prev = os.environ.get("CUDDH_PLAN_AFFINE")
+    os.environ["CUDDH_PLAN_AFFINE"] = "0"
+    try:
+        fs = cd.FaceSpace(fem, mesh.boundary_edges())
+        A = ShardedHelmholtz(cd, omega, np.ones(ndof), np.ones(fs.size()), mesh, fem, fs, rank, world, device=dev, host_staging=staged)
+    finally:
+        if prev is None:
+            del os.environ["CUDDH_PLAN_AFFINE"]
+        else:
+            os.environ["CUDDH_PLAN_AFFINE"] = prev
+    x = torch.rand(2 * A.n_loc, dtype=torch.float64, device=dev)
+    x.index_fill_(0, A.halo_idx, 0.0)
+    y = torch.empty_like(x)
+    for _ in range(3):
+        A.action(x, y)
+    torch.cuda.synchronize()
+    dist.barrier()
+    reps = 20
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        A.action(x, y)
+    torch.cuda.synchronize()
+    t = torch.tensor([(time.perf_counter() - t0) / reps], dtype=torch.float64, device=dev)
+    allred(t, dist.ReduceOp.MAX)
+    t = float(t.item())
+    n_elem, nb = mesh.n_elem(), fem.basis.n
+    nqS, nqM, nqF = nb + 1, 2 + 3 * nb // 2, 2 + 3 * nb // 2
+    b_alg = n_elem * (3 * nqS * nqS * 8 + nqM * nqM * 8 + nb * nb * 4) + ndof * 32 + fs.n_faces() * (nqF * 8 + nb * 4)
+    return {"label": "fused Helmholtz apply partitioned over the ranks (element partition + two halo exchanges per apply)",
+            "achieved": b_alg / t / 1e9, "unit": "GB/s", "seconds_per_apply": t, "algorithmic_bytes": b_alg,
+            "local_dofs_rank0": A.n_loc, "halo_dofs_rank0": int(A.part.halo.size)}
 
 
 def helmholtz_roofline(cd, torch, dev, fem, mesh, omega, ndof):
