@@ -1,5 +1,5 @@
 """DDH solve in the reference's fp32 and in the fp64 parity mode on the same problem: iteration counts, times and the
-relative l2 difference of the post-processed solutions.  usage: ddh_precision.py [nx] [maxit] [tol]"""
+relative l2 difference of the post-processed solutions.  usage: ddh_precision.py [nx] [maxit] [tol] [omega_over_pi]"""
 import math
 import sys
 import time
@@ -16,7 +16,7 @@ maxit = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 tol = float(sys.argv[3]) if len(sys.argv) > 3 else 1e-4
 dev = torch.device("cuda:0")
 cd.use_torch_stream()
-omega = math.pi * nx / 32.0
+omega = math.pi * (float(sys.argv[4]) if len(sys.argv) > 4 else nx / 32.0)
 fem = cd.H1Space(cd.Mesh2D.uniform_rect(nx, -1.0, 1.0, nx, -1.0, 1.0), cd.Basis(4))
 n = fem.size()
 f = torch.zeros(2 * n, dtype=torch.float64, device=dev)
