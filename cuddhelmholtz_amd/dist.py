@@ -410,31 +410,52 @@ class ShardedHelmholtz:
         self.halo_from = {s: idx(v) for s, v in p.halo_from.items()}
         self.halo_idx = idx(p.halo)
         self.owned_idx = idx(p.owned)
+        # one gather / scatter launch per exchange whatever the number of neighbours: concatenated index lists, per-neighbour
+        # messages are views into one buffer
+        cat = lambda d: (torch.cat([d[s] for s in sorted(d)]) if d else torch.zeros(0, dtype=torch.long, device=self.device))  # noqa: E731
+        self._own_cat, self._halo_cat = cat(self.own_to), cat(self.halo_from)
+        self._own_split = [(s, self.own_to[s].numel()) for s in sorted(self.own_to)]
+        self._halo_split = [(s, self.halo_from[s].numel()) for s in sorted(self.halo_from)]
         self._scratch = torch.zeros(2 * p.n_loc, dtype=torch.float64, device=self.device)
 
     # ---- the two exchanges, as pack / unpack pairs (an in-process replay of several ranks calls them directly)
+    @staticmethod
+    def _views(buf, split):
+        out, o = {}, 0
+        for s, n in split:
+            out[s] = buf[o:o + n]
+            o += n
+        return out
+
+    def _joined(self, received, split):
+        import torch
+
+        return torch.cat([received[s].to(self.device) for s, _ in split]) if split else None
+
     def pack_x(self, x):
-        return {s: x.index_select(0, idx) for s, idx in self.own_to.items()}
+        return self._views(x.index_select(0, self._own_cat), self._own_split)
 
     def unpack_x(self, x, received) -> None:
-        for s, idx in self.halo_from.items():
-            x.index_copy_(0, idx, received[s].to(x.device))
+        if self._halo_split:
+            x.index_copy_(0, self._halo_cat, self._joined(received, self._halo_split))
 
     def pack_y(self, y):
-        return {s: y.index_select(0, idx) for s, idx in self.halo_from.items()}
+        return self._views(y.index_select(0, self._halo_cat), self._halo_split)
 
     def unpack_y(self, y, received) -> None:
-        for s, idx in self.own_to.items():
-            y.index_add_(0, idx, received[s].to(y.device))
+        if self._own_split:
+            y.index_add_(0, self._own_cat, self._joined(received, self._own_split))
         y.index_fill_(0, self.halo_idx, 0.0)
 
-    def _exchange(self, outgoing, incoming_sizes):
+    def _exchange(self, outgoing, incoming_split):
         import torch
         import torch.distributed as dist
 
         stage = (lambda t: t.cpu()) if self.host_staging else (lambda t: t)  # noqa: E731
         sbuf = {s: stage(t.contiguous()) for s, t in outgoing.items()}
-        rbuf = {s: torch.empty(n, dtype=torch.float64, device="cpu" if self.host_staging else self.device) for s, n in incoming_sizes.items()}
+        total = sum(n for _, n in incoming_split)
+        rall = torch.empty(total, dtype=torch.float64, device="cpu" if self.host_staging else self.device)
+        rbuf = self._views(rall, incoming_split)
         ops = []
         for s in sorted(set(sbuf) | set(rbuf)):
             if s in sbuf:
@@ -450,10 +471,10 @@ class ShardedHelmholtz:
         xs = self._scratch
         xs.copy_(x)
         if self.world > 1:
-            self.unpack_x(xs, self._exchange(self.pack_x(xs), {s: i.numel() for s, i in self.halo_from.items()}))
+            self.unpack_x(xs, self._exchange(self.pack_x(xs), self._halo_split))
         self.op.action(xs, y)
         if self.world > 1:
-            self.unpack_y(y, self._exchange(self.pack_y(y), {s: i.numel() for s, i in self.own_to.items()}))
+            self.unpack_y(y, self._exchange(self.pack_y(y), self._own_split))
 
     def reduce(self, t) -> None:
         if self.world > 1:
