@@ -45,6 +45,9 @@ struct cuddh_helmholtz_plan
     // affine meshes (every element has the same metric array, e.g. uniform_rect): one copy, read through scalar loads
     double *Gu = nullptr; // [q][3][r]  (then Gp is not allocated)
     double *au = nullptr; // [q][r]     (then aMp is not allocated)
+    // high-order single operators on the fp64 matrix cores: batches of 16 elements, metric as [batch][r][3][q][16]
+    double *Gm = nullptr;
+    int pe = 32; // elements per patch (16 for the matrix-core plans)
     // faces, grouped by patch
     int *face_off = nullptr;       // [n_patches + 1]
     uint16_t *face_lidx = nullptr; // [n_faces_total][nb]
@@ -509,6 +512,25 @@ namespace
         return upload(table, t);
     }
 
+    // reference layout (c, q, r, el) -> [batch][r][c][q][16]  (matrix-core stiffness kernel: slices over the eta index r)
+    __global__ void __launch_bounds__(256) repack_mfma_kernel(long long total, int nq, const int *__restrict__ perm,
+                                                             const double *__restrict__ src, double *__restrict__ dst)
+    {
+        for (long long t = blockIdx.x * 256LL + threadIdx.x; t < total; t += gridDim.x * 256LL)
+        {
+            const int le = static_cast<int>(t % 16);
+            long long rest = t / 16;
+            const int q = static_cast<int>(rest % nq);
+            rest /= nq;
+            const int c = static_cast<int>(rest % 3);
+            rest /= 3;
+            const int r = static_cast<int>(rest % nq);
+            const long long batch = rest / nq;
+            const int el = perm[batch * 16 + le];
+            dst[t] = el >= 0 ? src[c + (size_t)3 * ((q + (size_t)nq * r) + (size_t)nq * nq * el)] : 0.0;
+        }
+    }
+
     // reference layout (c, q, r, el) -> [patch][q][c][r][32]
     __global__ void __launch_bounds__(256) repack_kernel(long long total, int comps, int nq, const int *__restrict__ perm,
                                                         const double *__restrict__ src, double *__restrict__ dst)
@@ -828,6 +850,205 @@ namespace
         }
     }
 
+    // ---------------------------------------------------------------- high-order stiffness on the fp64 matrix cores
+    // y = [y +] c * S x for 6 <= n_basis <= 8 (one element per lane needs more registers than a lane has there).  A
+    // wavefront takes a batch of 16 elements: lane = element + 16 g; lane group g holds the element's values u(k, l) for the
+    // xi-indices k = g and g + 4 and all eta-indices l.  Per eta-quadrature index r: the in-lane eta contraction gives the B
+    // operand of v_mfma_f64_16x16x4_f64 directly (B[k = lane / 16][n = lane % 16], k-step s <-> xi-index 4 s + g), A = the 1-D
+    // matrix D or P padded to 16 rows, and the product comes back in the C layout of the fp64 instruction -- register j of
+    // lane group g is row 4 j + g -- i.e. every lane holds the xi-quadrature rows q = g, g + 4, g + 8 of its element for the
+    // pointwise metric product.  That is again a B operand (k-step j <-> q = 4 j + g) for the contraction back over q, whose
+    // result lands in the layout u started in (k = 4 j + g): no shuffle anywhere.  10 MFMAs + ~110 fp64 VALU per slice; the
+    // metric array is streamed as [batch][r][3][q][16].  Colour phases, border slots, write-out: as op_patch_kernel.
+    typedef double mfma_d4 __attribute__((ext_vector_type(4)));
+
+    template <int NB, int NQ>
+    __global__ void __launch_bounds__(64, 2) op_mfma_kernel(HelmArgs A, int accumulate, const double *__restrict__ P, const double *__restrict__ D,
+                                                            const double *__restrict__ Gm)
+    {
+        static_assert(NB >= 5 && NB <= 8 && NQ <= 16, "xi-indices k = g + 4 s with s < 2");
+        constexpr int NN = NB * NB, NP = (NN + 1) / 2, PEM = 16;
+        constexpr int JQ = (NQ + 3) / 4; // registers / k-steps that carry quadrature rows
+        extern __shared__ double lds[];
+        const int patch = (blockIdx.x & 7) * A.xcd_chunk + (blockIdx.x >> 3);
+        if (patch >= A.n_patches)
+            return; // whole workgroup
+        const int lane = threadIdx.x, e = lane & 15, g = lane >> 4;
+        const int ML = A.max_loc;
+        double *xs = lds, *ys = lds + ML;
+        const int off = A.dof_off[patch];
+        const int nloc = A.dof_off[patch + 1] - off;
+        const int *dofs = A.dof_list + off;
+        const bool active = e < A.patch_nel[patch];
+        const int mycol = active ? A.colour[patch * PEM + e] : -1;
+        const uint32_t *li = A.lidx + (size_t)patch * NP * PEM + e;
+        // patch-local dofs of my nodes (k = g + 4 s, l): the same for the input and for the result
+        int id[2][NB];
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int l = 0; l < NB; ++l)
+            {
+                const int n = g + 4 * s + NB * l;
+                const uint32_t w = (g + 4 * s < NB) ? li[(n >> 1) * PEM] : 0u;
+                id[s][l] = (n & 1) ? static_cast<int>(w >> 16) : static_cast<int>(w & 0xFFFFu);
+            }
+
+        constexpr int ROWS = 8;
+        for (int base = 0; base < nloc; base += 64 * ROWS)
+        {
+            int gi[ROWS];
+#pragma unroll
+            for (int j = 0; j < ROWS; ++j)
+                gi[j] = dofs[min(base + 64 * j + lane, nloc - 1)];
+            double xv[ROWS];
+#pragma unroll
+            for (int j = 0; j < ROWS; ++j)
+                xv[j] = A.x[gi[j]];
+#pragma unroll
+            for (int j = 0; j < ROWS; ++j)
+            {
+                const int i = base + 64 * j + lane;
+                if (i < nloc)
+                {
+                    xs[i] = xv[j];
+                    ys[i] = 0.0;
+                }
+            }
+        }
+        __syncthreads();
+
+        double U[2][NB], OUT[2][NB];
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int l = 0; l < NB; ++l)
+            {
+                U[s][l] = (active && g + 4 * s < NB) ? xs[id[s][l]] : 0.0;
+                OUT[s][l] = 0.0;
+            }
+
+        // A operands: row i = lane % 16, column = 4 * step + lane / 16.  forward (rows q, columns k'): D(q, k'), P(q, k');
+        // backward (rows k, columns q): D(q, k), P(q, k)
+        double AfD[2], AfP[2], AbD[JQ], AbP[JQ];
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+        {
+            const int q = e, kp = 4 * s + g;
+            const bool ok = q < NQ && kp < NB;
+            AfD[s] = ok ? D[q + NQ * kp] : 0.0;
+            AfP[s] = ok ? P[q + NQ * kp] : 0.0;
+        }
+#pragma unroll
+        for (int sp = 0; sp < JQ; ++sp)
+        {
+            const int k = e, q = 4 * sp + g;
+            const bool ok = k < NB && q < NQ;
+            AbD[sp] = ok ? D[q + NQ * k] : 0.0;
+            AbP[sp] = ok ? P[q + NQ * k] : 0.0;
+        }
+
+        const double *Gb = Gm + (size_t)patch * NQ * 3 * NQ * PEM + e;
+#pragma unroll 1
+        for (int r = 0; r < NQ; ++r)
+        {
+            // metric at my quadrature rows q = 4 j + g
+            double ga[JQ], gb[JQ], gc[JQ];
+#pragma unroll
+            for (int j = 0; j < JQ; ++j)
+            {
+                const int q = 4 * j + g;
+                const bool ok = q < NQ;
+                const size_t o = (((size_t)r * 3) * NQ + (ok ? q : 0)) * PEM;
+                ga[j] = ok ? __builtin_nontemporal_load(&Gb[o]) : 0.0;
+                gb[j] = ok ? __builtin_nontemporal_load(&Gb[o + (size_t)NQ * PEM]) : 0.0;
+                gc[j] = ok ? __builtin_nontemporal_load(&Gb[o + (size_t)2 * NQ * PEM]) : 0.0;
+            }
+            double pl[2], dl[2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+            {
+                double a = 0.0, b = 0.0;
+#pragma unroll
+                for (int l = 0; l < NB; ++l)
+                {
+                    a += P[r + NQ * l] * U[s][l];
+                    b += D[r + NQ * l] * U[s][l];
+                }
+                pl[s] = a;
+                dl[s] = b;
+            }
+            // dx(q, r) = sum_k' D(q, k') pl_k'(r),  dy(q, r) = sum_k' P(q, k') dl_k'(r)
+            mfma_d4 dx = {0, 0, 0, 0}, dy = {0, 0, 0, 0};
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+            {
+                dx = __builtin_amdgcn_mfma_f64_16x16x4f64(AfD[s], pl[s], dx, 0, 0, 0);
+                dy = __builtin_amdgcn_mfma_f64_16x16x4f64(AfP[s], dl[s], dy, 0, 0, 0);
+            }
+            // W0(k) = sum_q D(q, k) F0(q, r),  W1(k) = sum_q P(q, k) F1(q, r)
+            mfma_d4 W0 = {0, 0, 0, 0}, W1 = {0, 0, 0, 0};
+#pragma unroll
+            for (int j = 0; j < JQ; ++j)
+            {
+                const double f0 = ga[j] * dx[j] + gb[j] * dy[j];
+                const double f1 = gb[j] * dx[j] + gc[j] * dy[j];
+                W0 = __builtin_amdgcn_mfma_f64_16x16x4f64(AbD[j], f0, W0, 0, 0, 0);
+                W1 = __builtin_amdgcn_mfma_f64_16x16x4f64(AbP[j], f1, W1, 0, 0, 0);
+            }
+            // out(k, l) += P(r, l) W0(k) + D(r, l) W1(k),  k = 4 s + g
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int l = 0; l < NB; ++l)
+                    OUT[s][l] += P[r + NQ * l] * W0[s] + D[r + NQ * l] * W1[s];
+        }
+
+        // accumulate in colour phases: the four lane groups of an element hold different nodes of it
+        for (int c = 0; c < A.ncol; ++c)
+        {
+            if (mycol == c)
+            {
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+                    if (g + 4 * s < NB)
+                    {
+#pragma unroll
+                        for (int l = 0; l < NB; ++l)
+                            ys[id[s][l]] += OUT[s][l];
+                    }
+            }
+            __syncthreads();
+        }
+
+        // write out (as op_patch_kernel)
+        const double cs = A.omega; // the scale factor travels in the omega field
+        const int *slot = A.slot_of + off;
+        for (int base = 0; base < nloc; base += 64 * ROWS)
+        {
+            int dest[ROWS];
+            double y0[ROWS];
+#pragma unroll
+            for (int j = 0; j < ROWS; ++j)
+                dest[j] = slot[min(base + 64 * j + lane, nloc - 1)];
+#pragma unroll
+            for (int j = 0; j < ROWS; ++j)
+                y0[j] = (accumulate && dest[j] >= 0) ? A.y[dest[j]] : 0.0;
+#pragma unroll
+            for (int j = 0; j < ROWS; ++j)
+            {
+                const int i = base + 64 * j + lane;
+                if (i >= nloc)
+                    continue;
+                const double val = cs * ys[i];
+                if (dest[j] >= 0)
+                    A.y[dest[j]] = y0[j] + val;
+                else
+                    A.part[-dest[j] - 1] = val;
+            }
+        }
+    }
+
     __global__ void __launch_bounds__(256) op_border_kernel(int n_shared, int accumulate, const int *__restrict__ shared_dof,
                                                            const int *__restrict__ shared_off,
                                                            const double *__restrict__ part, double *__restrict__ y)
@@ -843,9 +1064,14 @@ namespace
     }
 
     // kind 0: stiffness with nq = nb + 1; kind 1: mass with nq = nb + 1 (a == 1) or 1 + 3 nb / 2 + 1 (weighted)
+    // stiffness for 6 <= n_basis <= 8 runs on the fp64 matrix cores (op_mfma_kernel, 16-element batches)
+    bool op_mfma(int kind, int nb, int nq) { return kind == 0 && nb >= 6 && nb <= 8 && nq == nb + 1; }
+
     bool op_supported(int kind, int nb, int nq)
     {
-        if (nb < 2 || nb > 5) // n_basis 6 measured slower than the generic kernels here (256 VGPRs + spills at 2 waves/SIMD)
+        if (op_mfma(kind, nb, nq))
+            return true;
+        if (nb < 2 || nb > 5) // one element per lane: n_basis 6 measured slower than the generic kernels (256 VGPRs + spills)
             return false;
         if (kind == 0)
             return nq == nb + 1;
@@ -898,7 +1124,7 @@ extern "C"
     {
         if (!p)
             return 0;
-        void *ptrs[] = {p->dof_off, p->dof_list, p->slot_of, p->patch_nel, p->lidx, p->colour, p->Gp, p->aMp, p->Gu, p->au, p->face_off,
+        void *ptrs[] = {p->dof_off, p->dof_list, p->slot_of, p->patch_nel, p->lidx, p->colour, p->Gp, p->aMp, p->Gu, p->au, p->Gm, p->face_off,
                         p->face_lidx, p->face_id, p->face_col, p->PS, p->DS, p->PM, p->PF, p->shared_dof, p->shared_off,
                         p->part};
         for (void *q : ptrs)
@@ -911,9 +1137,11 @@ extern "C"
     // nqS == 0 or nqM == 0: a plan for a single real operator (the other tables are left empty)
     static int build_plan(cuddh_helmholtz_plan **out, int ndof, int n_elem, int nb, const int *h_I, const double *h_xy, int nqS,
                           const double *h_PS, const double *h_DS, const double *G_S, int nqM, const double *h_PM, const double *a_M,
-                          int n_faces, const int *h_fI, const int *h_face_elem, int nqF, const double *h_PF, const double *a_F)
+                          int n_faces, const int *h_fI, const int *h_face_elem, int nqF, const double *h_PF, const double *a_F,
+                          int pe = PE)
     {
         *out = nullptr;
+        const bool mfma = pe != PE; // 16-element batches: the matrix-core stiffness kernel
 
         cuddh_helmholtz_plan *p = new cuddh_helmholtz_plan;
         p->ndof = ndof;
@@ -956,13 +1184,14 @@ extern "C"
                 perm[e] = static_cast<int>(key[e] & 0xFFFFFFFFu);
         }
 
-        const int n_patches = (n_elem + PE - 1) / PE;
+        const int n_patches = (n_elem + pe - 1) / pe;
         p->n_patches = n_patches;
-        std::vector<int> padded_perm((size_t)n_patches * PE, -1);
+        p->pe = pe;
+        std::vector<int> padded_perm((size_t)n_patches * pe, -1);
         std::copy(perm.begin(), perm.end(), padded_perm.begin());
         std::vector<int> patch_of_elem(n_elem);
         for (int pos = 0; pos < n_elem; ++pos)
-            patch_of_elem[perm[pos]] = pos / PE;
+            patch_of_elem[perm[pos]] = pos / pe;
 
         // ---- faces bucketed by the patch of their element
         std::vector<int> face_off(n_patches + 1, 0);
@@ -980,9 +1209,9 @@ extern "C"
         // ---- patch-local numbering, colours
         std::vector<int> dof_off(n_patches + 1, 0), dof_list, patch_nel(n_patches);
         const int np2 = (nn + 1) / 2;
-        std::vector<uint32_t> lidx((size_t)n_patches * np2 * PE, 0);
+        std::vector<uint32_t> lidx((size_t)n_patches * np2 * pe, 0);
         std::vector<uint16_t> face_lidx((size_t)n_faces * nb, 0);
-        std::vector<uint8_t> colour((size_t)n_patches * PE, 0), face_col(n_faces, 0);
+        std::vector<uint8_t> colour((size_t)n_patches * pe, 0), face_col(n_faces, 0);
         std::vector<int> stamp(ndof, -1), loc(ndof, 0), touches(ndof, 0);
         std::vector<uint32_t> used, usedF;
         int max_loc = 0, ncol = 1, nfcol = 1;
@@ -991,12 +1220,12 @@ extern "C"
         {
             const int first = static_cast<int>(dof_list.size());
             dof_off[q] = first;
-            const int nel = std::min(PE, n_elem - q * PE);
+            const int nel = std::min(pe, n_elem - q * pe);
             patch_nel[q] = nel;
             used.clear();
             for (int le = 0; le < nel; ++le)
             {
-                const int *gi = h_I + (size_t)nn * perm[q * PE + le];
+                const int *gi = h_I + (size_t)nn * perm[q * pe + le];
                 uint32_t taken = 0;
                 for (int n = 0; n < nn; ++n)
                 {
@@ -1009,13 +1238,13 @@ extern "C"
                         touches[g]++;
                         used.push_back(0);
                     }
-                    lidx[((size_t)q * np2 + n / 2) * PE + le] |= static_cast<uint32_t>(loc[g]) << (16 * (n & 1));
+                    lidx[((size_t)q * np2 + n / 2) * pe + le] |= static_cast<uint32_t>(loc[g]) << (16 * (n & 1));
                     taken |= used[loc[g]];
                 }
                 int c = 0;
                 while (c < 31 && (taken >> c & 1u))
                     ++c;
-                colour[(size_t)q * PE + le] = static_cast<uint8_t>(c);
+                colour[(size_t)q * pe + le] = static_cast<uint8_t>(c);
                 ncol = std::max(ncol, c + 1);
                 for (int n = 0; n < nn; ++n)
                     used[loc[gi[n]]] |= 1u << c;
@@ -1115,19 +1344,23 @@ extern "C"
         bool try_affine = true;
         if (const char *e = std::getenv("CUDDH_PLAN_AFFINE"))
             try_affine = std::atoi(e) != 0;
+        if (mfma)
+            try_affine = false; // the matrix-core kernel always streams per-element metrics
         if (try_affine && nqS > 0)
             ok(uniform_table(&p->Gu, 3, nqS, n_elem, G_S));
         if (try_affine && nqM > 0 && nqS == 0) // the fused complex kernel always reads per-element mass weights (they carry a(x)^2)
             ok(uniform_table(&p->au, 1, nqM, n_elem, a_M));
-        const long long nG = p->Gu ? 0 : (long long)n_patches * 3 * nqS * nqS * PE;
-        const long long nA = p->au ? 0 : (long long)n_patches * nqM * nqM * PE;
+        const long long nG = p->Gu ? 0 : (long long)n_patches * 3 * nqS * nqS * pe;
+        const long long nA = p->au ? 0 : (long long)n_patches * nqM * nqM * pe;
         if (nG > 0)
-            ok(static_cast<int>(hipMalloc(reinterpret_cast<void **>(&p->Gp), nG * sizeof(double))));
+            ok(static_cast<int>(hipMalloc(reinterpret_cast<void **>(mfma ? &p->Gm : &p->Gp), nG * sizeof(double))));
         if (nA > 0)
             ok(static_cast<int>(hipMalloc(reinterpret_cast<void **>(&p->aMp), nA * sizeof(double))));
         if (!err)
         {
-            if (nG > 0)
+            if (nG > 0 && mfma)
+                hipLaunchKernelGGL(repack_mfma_kernel, dim3(stream_grid(nG, 256)), dim3(256), 0, nullptr, nG, nqS, d_perm, G_S, p->Gm);
+            else if (nG > 0)
                 hipLaunchKernelGGL(repack_kernel, dim3(stream_grid(nG, 256)), dim3(256), 0, nullptr, nG, 3, nqS, d_perm, G_S, p->Gp);
             if (nA > 0)
                 hipLaunchKernelGGL(repack_kernel, dim3(stream_grid(nA, 256)), dim3(256), 0, nullptr, nA, 1, nqM, d_perm, a_M, p->aMp);
@@ -1181,7 +1414,7 @@ extern "C"
             return static_cast<int>(hipErrorNotSupported);
         if (kind == 0)
             return build_plan(out, ndof, n_elem, nb, h_I, h_xy, nq, h_P, h_D, metric, 0, nullptr, nullptr, 0, nullptr, nullptr, 0,
-                              nullptr, nullptr);
+                              nullptr, nullptr, op_mfma(kind, nb, nq) ? 16 : PE);
         return build_plan(out, ndof, n_elem, nb, h_I, h_xy, 0, nullptr, nullptr, nullptr, nq, h_P, metric, 0, nullptr, nullptr, 0,
                           nullptr, nullptr);
     }
@@ -1193,10 +1426,24 @@ extern "C"
         hipStream_t st = as_stream(stream);
         HelmArgs A = plan_args(p, x, y);
         A.omega = c;
-        const int n_pairs = (p->n_patches + 1) / 2;
-        A.xcd_chunk = (n_pairs + 7) / 8;
-        if (!launch_op(p, A, accumulate, st))
-            return static_cast<int>(hipErrorNotSupported);
+        if (p->Gm) // 16-element batches on the fp64 matrix cores, one batch per wavefront
+        {
+            const size_t lds = (size_t)2 * p->max_loc * sizeof(double);
+            const dim3 grid(8 * A.xcd_chunk), block(64);
+            if (p->nb == 6)
+                hipLaunchKernelGGL((op_mfma_kernel<6, 7>), grid, block, lds, st, A, accumulate, p->PS, p->DS, p->Gm);
+            else if (p->nb == 7)
+                hipLaunchKernelGGL((op_mfma_kernel<7, 8>), grid, block, lds, st, A, accumulate, p->PS, p->DS, p->Gm);
+            else
+                hipLaunchKernelGGL((op_mfma_kernel<8, 9>), grid, block, lds, st, A, accumulate, p->PS, p->DS, p->Gm);
+        }
+        else
+        {
+            const int n_pairs = (p->n_patches + 1) / 2;
+            A.xcd_chunk = (n_pairs + 7) / 8;
+            if (!launch_op(p, A, accumulate, st))
+                return static_cast<int>(hipErrorNotSupported);
+        }
         int err = launch_status();
         if (err)
             return err;
