@@ -512,8 +512,8 @@ namespace
         return upload(table, t);
     }
 
-    // reference layout (c, q, r, el) -> [batch][r][c][q][16]  (matrix-core stiffness kernel: slices over the eta index r)
-    __global__ void __launch_bounds__(256) repack_mfma_kernel(long long total, int nq, const int *__restrict__ perm,
+    // reference layout (c, q, r, el) -> [batch][r][c][q][16]  (matrix-core kernels: slices over the eta index r)
+    __global__ void __launch_bounds__(256) repack_mfma_kernel(long long total, int comps, int nq, const int *__restrict__ perm,
                                                              const double *__restrict__ src, double *__restrict__ dst)
     {
         for (long long t = blockIdx.x * 256LL + threadIdx.x; t < total; t += gridDim.x * 256LL)
@@ -522,12 +522,12 @@ namespace
             long long rest = t / 16;
             const int q = static_cast<int>(rest % nq);
             rest /= nq;
-            const int c = static_cast<int>(rest % 3);
-            rest /= 3;
+            const int c = static_cast<int>(rest % comps);
+            rest /= comps;
             const int r = static_cast<int>(rest % nq);
             const long long batch = rest / nq;
             const int el = perm[batch * 16 + le];
-            dst[t] = el >= 0 ? src[c + (size_t)3 * ((q + (size_t)nq * r) + (size_t)nq * nq * el)] : 0.0;
+            dst[t] = el >= 0 ? src[c + (size_t)comps * ((q + (size_t)nq * r) + (size_t)nq * nq * el)] : 0.0;
         }
     }
 
@@ -862,7 +862,9 @@ namespace
     // metric array is streamed as [batch][r][3][q][16].  Colour phases, border slots, write-out: as op_patch_kernel.
     typedef double mfma_d4 __attribute__((ext_vector_type(4)));
 
-    template <int NB, int NQ>
+    // KIND 1: the mass operator in the same scheme -- per slice one forward product v = P pl, the weight a(q, r), one backward
+    // product; metric [batch][r][q][16]
+    template <int NB, int NQ, int KIND>
     __global__ void __launch_bounds__(64, 2) op_mfma_kernel(HelmArgs A, int accumulate, const double *__restrict__ P, const double *__restrict__ D,
                                                             const double *__restrict__ Gm)
     {
@@ -936,7 +938,7 @@ namespace
         {
             const int q = e, kp = 4 * s + g;
             const bool ok = q < NQ && kp < NB;
-            AfD[s] = ok ? D[q + NQ * kp] : 0.0;
+            AfD[s] = (KIND == 0 && ok) ? D[q + NQ * kp] : 0.0;
             AfP[s] = ok ? P[q + NQ * kp] : 0.0;
         }
 #pragma unroll
@@ -944,64 +946,105 @@ namespace
         {
             const int k = e, q = 4 * sp + g;
             const bool ok = k < NB && q < NQ;
-            AbD[sp] = ok ? D[q + NQ * k] : 0.0;
+            AbD[sp] = (KIND == 0 && ok) ? D[q + NQ * k] : 0.0;
             AbP[sp] = ok ? P[q + NQ * k] : 0.0;
         }
 
-        const double *Gb = Gm + (size_t)patch * NQ * 3 * NQ * PEM + e;
-#pragma unroll 1
-        for (int r = 0; r < NQ; ++r)
+        if constexpr (KIND == 0)
         {
-            // metric at my quadrature rows q = 4 j + g
-            double ga[JQ], gb[JQ], gc[JQ];
-#pragma unroll
-            for (int j = 0; j < JQ; ++j)
+            const double *Gb = Gm + (size_t)patch * NQ * 3 * NQ * PEM + e;
+#pragma unroll 1
+            for (int r = 0; r < NQ; ++r)
             {
-                const int q = 4 * j + g;
-                const bool ok = q < NQ;
-                const size_t o = (((size_t)r * 3) * NQ + (ok ? q : 0)) * PEM;
-                ga[j] = ok ? __builtin_nontemporal_load(&Gb[o]) : 0.0;
-                gb[j] = ok ? __builtin_nontemporal_load(&Gb[o + (size_t)NQ * PEM]) : 0.0;
-                gc[j] = ok ? __builtin_nontemporal_load(&Gb[o + (size_t)2 * NQ * PEM]) : 0.0;
-            }
-            double pl[2], dl[2];
+                // metric at my quadrature rows q = 4 j + g
+                double ga[JQ], gb[JQ], gc[JQ];
 #pragma unroll
-            for (int s = 0; s < 2; ++s)
-            {
-                double a = 0.0, b = 0.0;
-#pragma unroll
-                for (int l = 0; l < NB; ++l)
+                for (int j = 0; j < JQ; ++j)
                 {
-                    a += P[r + NQ * l] * U[s][l];
-                    b += D[r + NQ * l] * U[s][l];
+                    const int q = 4 * j + g;
+                    const bool ok = q < NQ;
+                    const size_t o = (((size_t)r * 3) * NQ + (ok ? q : 0)) * PEM;
+                    ga[j] = ok ? __builtin_nontemporal_load(&Gb[o]) : 0.0;
+                    gb[j] = ok ? __builtin_nontemporal_load(&Gb[o + (size_t)NQ * PEM]) : 0.0;
+                    gc[j] = ok ? __builtin_nontemporal_load(&Gb[o + (size_t)2 * NQ * PEM]) : 0.0;
                 }
-                pl[s] = a;
-                dl[s] = b;
-            }
-            // dx(q, r) = sum_k' D(q, k') pl_k'(r),  dy(q, r) = sum_k' P(q, k') dl_k'(r)
-            mfma_d4 dx = {0, 0, 0, 0}, dy = {0, 0, 0, 0};
+                double pl[2], dl[2];
 #pragma unroll
-            for (int s = 0; s < 2; ++s)
+                for (int s = 0; s < 2; ++s)
+                {
+                    double a = 0.0, b = 0.0;
+#pragma unroll
+                    for (int l = 0; l < NB; ++l)
+                    {
+                        a += P[r + NQ * l] * U[s][l];
+                        b += D[r + NQ * l] * U[s][l];
+                    }
+                    pl[s] = a;
+                    dl[s] = b;
+                }
+                // dx(q, r) = sum_k' D(q, k') pl_k'(r),  dy(q, r) = sum_k' P(q, k') dl_k'(r)
+                mfma_d4 dx = {0, 0, 0, 0}, dy = {0, 0, 0, 0};
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+                {
+                    dx = __builtin_amdgcn_mfma_f64_16x16x4f64(AfD[s], pl[s], dx, 0, 0, 0);
+                    dy = __builtin_amdgcn_mfma_f64_16x16x4f64(AfP[s], dl[s], dy, 0, 0, 0);
+                }
+                // W0(k) = sum_q D(q, k) F0(q, r),  W1(k) = sum_q P(q, k) F1(q, r)
+                mfma_d4 W0 = {0, 0, 0, 0}, W1 = {0, 0, 0, 0};
+#pragma unroll
+                for (int j = 0; j < JQ; ++j)
+                {
+                    const double f0 = ga[j] * dx[j] + gb[j] * dy[j];
+                    const double f1 = gb[j] * dx[j] + gc[j] * dy[j];
+                    W0 = __builtin_amdgcn_mfma_f64_16x16x4f64(AbD[j], f0, W0, 0, 0, 0);
+                    W1 = __builtin_amdgcn_mfma_f64_16x16x4f64(AbP[j], f1, W1, 0, 0, 0);
+                }
+                // out(k, l) += P(r, l) W0(k) + D(r, l) W1(k),  k = 4 s + g
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int l = 0; l < NB; ++l)
+                        OUT[s][l] += P[r + NQ * l] * W0[s] + D[r + NQ * l] * W1[s];
+            }
+        }
+        else
+        {
+            const double *ab = Gm + (size_t)patch * NQ * NQ * PEM + e;
+#pragma unroll 1
+            for (int r = 0; r < NQ; ++r)
             {
-                dx = __builtin_amdgcn_mfma_f64_16x16x4f64(AfD[s], pl[s], dx, 0, 0, 0);
-                dy = __builtin_amdgcn_mfma_f64_16x16x4f64(AfP[s], dl[s], dy, 0, 0, 0);
+                double am[JQ];
+#pragma unroll
+                for (int j = 0; j < JQ; ++j)
+                {
+                    const int q = 4 * j + g;
+                    am[j] = q < NQ ? __builtin_nontemporal_load(&ab[((size_t)r * NQ + q) * PEM]) : 0.0;
+                }
+                double pl[2];
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+                {
+                    double a = 0.0;
+#pragma unroll
+                    for (int l = 0; l < NB; ++l)
+                        a += P[r + NQ * l] * U[s][l];
+                    pl[s] = a;
+                }
+                // v(q, r) = sum_k' P(q, k') pl_k'(r);  W(k) = sum_q P(q, k) a(q, r) v(q, r)
+                mfma_d4 v = {0, 0, 0, 0}, W = {0, 0, 0, 0};
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+                    v = __builtin_amdgcn_mfma_f64_16x16x4f64(AfP[s], pl[s], v, 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < JQ; ++j)
+                    W = __builtin_amdgcn_mfma_f64_16x16x4f64(AbP[j], am[j] * v[j], W, 0, 0, 0);
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int l = 0; l < NB; ++l)
+                        OUT[s][l] += P[r + NQ * l] * W[s];
             }
-            // W0(k) = sum_q D(q, k) F0(q, r),  W1(k) = sum_q P(q, k) F1(q, r)
-            mfma_d4 W0 = {0, 0, 0, 0}, W1 = {0, 0, 0, 0};
-#pragma unroll
-            for (int j = 0; j < JQ; ++j)
-            {
-                const double f0 = ga[j] * dx[j] + gb[j] * dy[j];
-                const double f1 = gb[j] * dx[j] + gc[j] * dy[j];
-                W0 = __builtin_amdgcn_mfma_f64_16x16x4f64(AbD[j], f0, W0, 0, 0, 0);
-                W1 = __builtin_amdgcn_mfma_f64_16x16x4f64(AbP[j], f1, W1, 0, 0, 0);
-            }
-            // out(k, l) += P(r, l) W0(k) + D(r, l) W1(k),  k = 4 s + g
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int l = 0; l < NB; ++l)
-                    OUT[s][l] += P[r + NQ * l] * W0[s] + D[r + NQ * l] * W1[s];
         }
 
         // accumulate in colour phases: the four lane groups of an element hold different nodes of it
@@ -1065,7 +1108,12 @@ namespace
 
     // kind 0: stiffness with nq = nb + 1; kind 1: mass with nq = nb + 1 (a == 1) or 1 + 3 nb / 2 + 1 (weighted)
     // stiffness for 6 <= n_basis <= 8 runs on the fp64 matrix cores (op_mfma_kernel, 16-element batches)
-    bool op_mfma(int kind, int nb, int nq) { return kind == 0 && nb >= 6 && nb <= 8 && nq == nb + 1; }
+    bool op_mfma(int kind, int nb, int nq)
+    {
+        if (nb < 6 || nb > 8)
+            return false;
+        return (kind == 0 && nq == nb + 1) || (kind == 1 && (nq == nb + 1 || nq == 2 + 3 * nb / 2));
+    }
 
     bool op_supported(int kind, int nb, int nq)
     {
@@ -1355,14 +1403,16 @@ extern "C"
         if (nG > 0)
             ok(static_cast<int>(hipMalloc(reinterpret_cast<void **>(mfma ? &p->Gm : &p->Gp), nG * sizeof(double))));
         if (nA > 0)
-            ok(static_cast<int>(hipMalloc(reinterpret_cast<void **>(&p->aMp), nA * sizeof(double))));
+            ok(static_cast<int>(hipMalloc(reinterpret_cast<void **>(mfma ? &p->Gm : &p->aMp), nA * sizeof(double))));
         if (!err)
         {
             if (nG > 0 && mfma)
-                hipLaunchKernelGGL(repack_mfma_kernel, dim3(stream_grid(nG, 256)), dim3(256), 0, nullptr, nG, nqS, d_perm, G_S, p->Gm);
+                hipLaunchKernelGGL(repack_mfma_kernel, dim3(stream_grid(nG, 256)), dim3(256), 0, nullptr, nG, 3, nqS, d_perm, G_S, p->Gm);
             else if (nG > 0)
                 hipLaunchKernelGGL(repack_kernel, dim3(stream_grid(nG, 256)), dim3(256), 0, nullptr, nG, 3, nqS, d_perm, G_S, p->Gp);
-            if (nA > 0)
+            if (nA > 0 && mfma)
+                hipLaunchKernelGGL(repack_mfma_kernel, dim3(stream_grid(nA, 256)), dim3(256), 0, nullptr, nA, 1, nqM, d_perm, a_M, p->Gm);
+            else if (nA > 0)
                 hipLaunchKernelGGL(repack_kernel, dim3(stream_grid(nA, 256)), dim3(256), 0, nullptr, nA, 1, nqM, d_perm, a_M, p->aMp);
             ok(launch_status());
             ok(static_cast<int>(hipDeviceSynchronize()));
@@ -1412,11 +1462,12 @@ extern "C"
         *out = nullptr;
         if (n_elem <= 0 || !op_supported(kind, nb, nq))
             return static_cast<int>(hipErrorNotSupported);
+        const int pe = op_mfma(kind, nb, nq) ? 16 : PE;
         if (kind == 0)
             return build_plan(out, ndof, n_elem, nb, h_I, h_xy, nq, h_P, h_D, metric, 0, nullptr, nullptr, 0, nullptr, nullptr, 0,
-                              nullptr, nullptr, op_mfma(kind, nb, nq) ? 16 : PE);
+                              nullptr, nullptr, pe);
         return build_plan(out, ndof, n_elem, nb, h_I, h_xy, 0, nullptr, nullptr, nullptr, nq, h_P, metric, 0, nullptr, nullptr, 0,
-                          nullptr, nullptr);
+                          nullptr, nullptr, pe);
     }
 
     int cuddh_hip_operator_plan_apply(const cuddh_helmholtz_plan *p, double c, int accumulate, const double *x, double *y, void *stream)
@@ -1430,12 +1481,27 @@ extern "C"
         {
             const size_t lds = (size_t)2 * p->max_loc * sizeof(double);
             const dim3 grid(8 * A.xcd_chunk), block(64);
-            if (p->nb == 6)
-                hipLaunchKernelGGL((op_mfma_kernel<6, 7>), grid, block, lds, st, A, accumulate, p->PS, p->DS, p->Gm);
-            else if (p->nb == 7)
-                hipLaunchKernelGGL((op_mfma_kernel<7, 8>), grid, block, lds, st, A, accumulate, p->PS, p->DS, p->Gm);
-            else
-                hipLaunchKernelGGL((op_mfma_kernel<8, 9>), grid, block, lds, st, A, accumulate, p->PS, p->DS, p->Gm);
+            const int kind = p->nqS > 0 ? 0 : 1, nq = kind == 0 ? p->nqS : p->nqM;
+            const double *P = kind == 0 ? p->PS : p->PM;
+            bool launched = false;
+#define CUDDH_MFMA_CASE(NB_, NQ_, K_)                                                                              \
+    if (!launched && p->nb == NB_ && nq == NQ_ && kind == K_)                                                      \
+    {                                                                                                              \
+        hipLaunchKernelGGL((op_mfma_kernel<NB_, NQ_, K_>), grid, block, lds, st, A, accumulate, P, p->DS, p->Gm);  \
+        launched = true;                                                                                           \
+    }
+            CUDDH_MFMA_CASE(6, 7, 0)
+            CUDDH_MFMA_CASE(7, 8, 0)
+            CUDDH_MFMA_CASE(8, 9, 0)
+            CUDDH_MFMA_CASE(6, 7, 1)
+            CUDDH_MFMA_CASE(7, 8, 1)
+            CUDDH_MFMA_CASE(8, 9, 1)
+            CUDDH_MFMA_CASE(6, 11, 1)
+            CUDDH_MFMA_CASE(7, 12, 1)
+            CUDDH_MFMA_CASE(8, 14, 1)
+#undef CUDDH_MFMA_CASE
+            if (!launched)
+                return static_cast<int>(hipErrorNotSupported);
         }
         else
         {
