@@ -47,6 +47,7 @@ struct cuddh_helmholtz_plan
     double *au = nullptr; // [q][r]     (then aMp is not allocated)
     // high-order single operators on the fp64 matrix cores: batches of 16 elements, metric as [batch][r][3][q][16]
     double *Gm = nullptr;
+    long long gm_stride = 0; // doubles between the metric blocks of consecutive batches; 0: one block for all (affine mesh)
     int pe = 32; // elements per patch (16 for the matrix-core plans)
     // faces, grouped by patch
     int *face_off = nullptr;       // [n_patches + 1]
@@ -866,7 +867,7 @@ namespace
     // product; metric [batch][r][q][16]
     template <int NB, int NQ, int KIND>
     __global__ void __launch_bounds__(64, 2) op_mfma_kernel(HelmArgs A, int accumulate, const double *__restrict__ P, const double *__restrict__ D,
-                                                            const double *__restrict__ Gm)
+                                                            const double *__restrict__ Gm, long long gm_stride)
     {
         static_assert(NB >= 5 && NB <= 8 && NQ <= 16, "xi-indices k = g + 4 s with s < 2");
         constexpr int NN = NB * NB, NP = (NN + 1) / 2, PEM = 16;
@@ -952,7 +953,7 @@ namespace
 
         if constexpr (KIND == 0)
         {
-            const double *Gb = Gm + (size_t)patch * NQ * 3 * NQ * PEM + e;
+            const double *Gb = Gm + (size_t)patch * gm_stride + e; // gm_stride == 0: affine mesh, one block for every batch
 #pragma unroll 1
             for (int r = 0; r < NQ; ++r)
             {
@@ -1010,7 +1011,7 @@ namespace
         }
         else
         {
-            const double *ab = Gm + (size_t)patch * NQ * NQ * PEM + e;
+            const double *ab = Gm + (size_t)patch * gm_stride + e;
 #pragma unroll 1
             for (int r = 0; r < NQ; ++r)
             {
@@ -1392,14 +1393,24 @@ extern "C"
         bool try_affine = true;
         if (const char *e = std::getenv("CUDDH_PLAN_AFFINE"))
             try_affine = std::atoi(e) != 0;
-        if (mfma)
-            try_affine = false; // the matrix-core kernel always streams per-element metrics
-        if (try_affine && nqS > 0)
+        bool mfma_uniform = false;
+        if (mfma && try_affine)
+        {
+            // matrix-core plans: a uniform metric array becomes ONE 16-element block that every batch reads (stride 0)
+            double *probe = nullptr;
+            ok(uniform_table(&probe, nqS > 0 ? 3 : 1, nqS > 0 ? nqS : nqM, n_elem, nqS > 0 ? G_S : a_M));
+            mfma_uniform = probe != nullptr;
+            if (probe)
+                (void)hipFree(probe);
+        }
+        if (try_affine && !mfma && nqS > 0)
             ok(uniform_table(&p->Gu, 3, nqS, n_elem, G_S));
-        if (try_affine && nqM > 0 && nqS == 0) // the fused complex kernel always reads per-element mass weights (they carry a(x)^2)
+        if (try_affine && !mfma && nqM > 0 && nqS == 0) // the fused complex kernel always reads per-element mass weights (they carry a(x)^2)
             ok(uniform_table(&p->au, 1, nqM, n_elem, a_M));
-        const long long nG = p->Gu ? 0 : (long long)n_patches * 3 * nqS * nqS * pe;
-        const long long nA = p->au ? 0 : (long long)n_patches * nqM * nqM * pe;
+        if (mfma_uniform && d_perm)
+            ok(static_cast<int>(hipMemset(d_perm, 0, (size_t)pe * sizeof(int)))); // the one block: element 0 in all 16 lanes
+        const long long nG = p->Gu ? 0 : (long long)(mfma_uniform ? 1 : n_patches) * 3 * nqS * nqS * pe;
+        const long long nA = p->au ? 0 : (long long)(mfma_uniform ? 1 : n_patches) * nqM * nqM * pe;
         if (nG > 0)
             ok(static_cast<int>(hipMalloc(reinterpret_cast<void **>(mfma ? &p->Gm : &p->Gp), nG * sizeof(double))));
         if (nA > 0)
@@ -1437,6 +1448,12 @@ extern "C"
                           (size_t)n_faces * ((size_t)nqF * 8 + (size_t)nb * 2 + 5);
         if (p->Gu || p->au) // SURVEY 8d's "affine" figure: the uniform metric arrays are not traffic
             p->bytes_affine = p->bytes_alg - (size_t)n_elem * ((p->Gu ? (size_t)3 * nqS * nqS * 8 : 0) + (p->au ? (size_t)nqM * nqM * 8 : 0));
+        if (mfma)
+        {
+            p->gm_stride = mfma_uniform ? 0 : (long long)(nqS > 0 ? 3 * nqS * nqS : nqM * nqM) * pe;
+            if (mfma_uniform)
+                p->bytes_affine = p->bytes_alg - (size_t)n_elem * ((size_t)3 * nqS * nqS * 8 + (size_t)nqM * nqM * 8);
+        }
         p->streaming = p->bytes_actual > (size_t)256 << 20; // the infinity cache
         if (const char *e = std::getenv("CUDDH_PLAN_STREAMING")) // measurement knob: 0 / 1 overrides the size rule
             p->streaming = std::atoi(e) != 0;
@@ -1487,7 +1504,7 @@ extern "C"
 #define CUDDH_MFMA_CASE(NB_, NQ_, K_)                                                                              \
     if (!launched && p->nb == NB_ && nq == NQ_ && kind == K_)                                                      \
     {                                                                                                              \
-        hipLaunchKernelGGL((op_mfma_kernel<NB_, NQ_, K_>), grid, block, lds, st, A, accumulate, P, p->DS, p->Gm);  \
+        hipLaunchKernelGGL((op_mfma_kernel<NB_, NQ_, K_>), grid, block, lds, st, A, accumulate, P, p->DS, p->Gm, p->gm_stride);  \
         launched = true;                                                                                           \
     }
             CUDDH_MFMA_CASE(6, 7, 0)
