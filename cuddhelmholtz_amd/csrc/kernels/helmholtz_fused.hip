@@ -46,8 +46,8 @@ struct cuddh_helmholtz_plan
     double *Gu = nullptr; // [q][3][r]  (then Gp is not allocated)
     double *au = nullptr; // [q][r]     (then aMp is not allocated)
     // high-order single operators on the fp64 matrix cores: batches of 16 elements, metric as [batch][r][3][q][16]
-    double *Gm = nullptr;
-    long long gm_stride = 0; // doubles between the metric blocks of consecutive batches; 0: one block for all (affine mesh)
+    double *Gm = nullptr, *Am = nullptr; // stiffness metric, mass weights ([batch][r][q][16])
+    long long gm_stride = 0, am_stride = 0; // doubles between the blocks of consecutive batches; 0: one block for all (affine mesh)
     int pe = 32; // elements per patch (16 for the matrix-core plans)
     // faces, grouped by patch
     int *face_off = nullptr;       // [n_patches + 1]
@@ -1173,7 +1173,7 @@ extern "C"
     {
         if (!p)
             return 0;
-        void *ptrs[] = {p->dof_off, p->dof_list, p->slot_of, p->patch_nel, p->lidx, p->colour, p->Gp, p->aMp, p->Gu, p->au, p->Gm, p->face_off,
+        void *ptrs[] = {p->dof_off, p->dof_list, p->slot_of, p->patch_nel, p->lidx, p->colour, p->Gp, p->aMp, p->Gu, p->au, p->Gm, p->Am, p->face_off,
                         p->face_lidx, p->face_id, p->face_col, p->PS, p->DS, p->PM, p->PF, p->shared_dof, p->shared_off,
                         p->part};
         for (void *q : ptrs)
@@ -1393,41 +1393,60 @@ extern "C"
         bool try_affine = true;
         if (const char *e = std::getenv("CUDDH_PLAN_AFFINE"))
             try_affine = std::atoi(e) != 0;
-        bool mfma_uniform = false;
+        bool uniform_G = false, uniform_a = false; // matrix-core plans: a uniform array becomes ONE 16-element block (stride 0)
         if (mfma && try_affine)
         {
-            // matrix-core plans: a uniform metric array becomes ONE 16-element block that every batch reads (stride 0)
             double *probe = nullptr;
-            ok(uniform_table(&probe, nqS > 0 ? 3 : 1, nqS > 0 ? nqS : nqM, n_elem, nqS > 0 ? G_S : a_M));
-            mfma_uniform = probe != nullptr;
-            if (probe)
-                (void)hipFree(probe);
+            if (nqS > 0)
+            {
+                ok(uniform_table(&probe, 3, nqS, n_elem, G_S));
+                uniform_G = probe != nullptr;
+                if (probe)
+                    (void)hipFree(probe);
+            }
+            if (nqM > 0)
+            {
+                probe = nullptr;
+                ok(uniform_table(&probe, 1, nqM, n_elem, a_M));
+                uniform_a = probe != nullptr;
+                if (probe)
+                    (void)hipFree(probe);
+            }
         }
         if (try_affine && !mfma && nqS > 0)
             ok(uniform_table(&p->Gu, 3, nqS, n_elem, G_S));
         if (try_affine && !mfma && nqM > 0 && nqS == 0) // the fused complex kernel always reads per-element mass weights (they carry a(x)^2)
             ok(uniform_table(&p->au, 1, nqM, n_elem, a_M));
-        if (mfma_uniform && d_perm)
-            ok(static_cast<int>(hipMemset(d_perm, 0, (size_t)pe * sizeof(int)))); // the one block: element 0 in all 16 lanes
-        const long long nG = p->Gu ? 0 : (long long)(mfma_uniform ? 1 : n_patches) * 3 * nqS * nqS * pe;
-        const long long nA = p->au ? 0 : (long long)(mfma_uniform ? 1 : n_patches) * nqM * nqM * pe;
+        int *d_zero = nullptr; // "element 0 in all 16 lanes": the one block of a uniform array
+        if (uniform_G || uniform_a)
+        {
+            ok(static_cast<int>(hipMalloc(reinterpret_cast<void **>(&d_zero), (size_t)pe * sizeof(int))));
+            if (d_zero)
+                ok(static_cast<int>(hipMemset(d_zero, 0, (size_t)pe * sizeof(int))));
+        }
+        const long long nG = p->Gu ? 0 : (long long)(uniform_G ? 1 : n_patches) * 3 * nqS * nqS * pe;
+        const long long nA = p->au ? 0 : (long long)(uniform_a ? 1 : n_patches) * nqM * nqM * pe;
         if (nG > 0)
             ok(static_cast<int>(hipMalloc(reinterpret_cast<void **>(mfma ? &p->Gm : &p->Gp), nG * sizeof(double))));
         if (nA > 0)
-            ok(static_cast<int>(hipMalloc(reinterpret_cast<void **>(mfma ? &p->Gm : &p->aMp), nA * sizeof(double))));
+            ok(static_cast<int>(hipMalloc(reinterpret_cast<void **>(mfma ? &p->Am : &p->aMp), nA * sizeof(double))));
         if (!err)
         {
             if (nG > 0 && mfma)
-                hipLaunchKernelGGL(repack_mfma_kernel, dim3(stream_grid(nG, 256)), dim3(256), 0, nullptr, nG, 3, nqS, d_perm, G_S, p->Gm);
+                hipLaunchKernelGGL(repack_mfma_kernel, dim3(stream_grid(nG, 256)), dim3(256), 0, nullptr, nG, 3, nqS, uniform_G ? d_zero : d_perm, G_S,
+                                   p->Gm);
             else if (nG > 0)
                 hipLaunchKernelGGL(repack_kernel, dim3(stream_grid(nG, 256)), dim3(256), 0, nullptr, nG, 3, nqS, d_perm, G_S, p->Gp);
             if (nA > 0 && mfma)
-                hipLaunchKernelGGL(repack_mfma_kernel, dim3(stream_grid(nA, 256)), dim3(256), 0, nullptr, nA, 1, nqM, d_perm, a_M, p->Gm);
+                hipLaunchKernelGGL(repack_mfma_kernel, dim3(stream_grid(nA, 256)), dim3(256), 0, nullptr, nA, 1, nqM, uniform_a ? d_zero : d_perm, a_M,
+                                   p->Am);
             else if (nA > 0)
                 hipLaunchKernelGGL(repack_kernel, dim3(stream_grid(nA, 256)), dim3(256), 0, nullptr, nA, 1, nqM, d_perm, a_M, p->aMp);
             ok(launch_status());
             ok(static_cast<int>(hipDeviceSynchronize()));
         }
+        if (d_zero)
+            (void)hipFree(d_zero);
         if (d_perm)
             (void)hipFree(d_perm);
         if (err)
@@ -1450,9 +1469,10 @@ extern "C"
             p->bytes_affine = p->bytes_alg - (size_t)n_elem * ((p->Gu ? (size_t)3 * nqS * nqS * 8 : 0) + (p->au ? (size_t)nqM * nqM * 8 : 0));
         if (mfma)
         {
-            p->gm_stride = mfma_uniform ? 0 : (long long)(nqS > 0 ? 3 * nqS * nqS : nqM * nqM) * pe;
-            if (mfma_uniform)
-                p->bytes_affine = p->bytes_alg - (size_t)n_elem * ((size_t)3 * nqS * nqS * 8 + (size_t)nqM * nqM * 8);
+            p->gm_stride = uniform_G ? 0 : (long long)3 * nqS * nqS * pe;
+            p->am_stride = uniform_a ? 0 : (long long)nqM * nqM * pe;
+            if (uniform_G || uniform_a)
+                p->bytes_affine = p->bytes_alg - (size_t)n_elem * ((uniform_G ? (size_t)3 * nqS * nqS * 8 : 0) + (uniform_a ? (size_t)nqM * nqM * 8 : 0));
         }
         p->streaming = p->bytes_actual > (size_t)256 << 20; // the infinity cache
         if (const char *e = std::getenv("CUDDH_PLAN_STREAMING")) // measurement knob: 0 / 1 overrides the size rule
@@ -1494,7 +1514,7 @@ extern "C"
         hipStream_t st = as_stream(stream);
         HelmArgs A = plan_args(p, x, y);
         A.omega = c;
-        if (p->Gm) // 16-element batches on the fp64 matrix cores, one batch per wavefront
+        if (p->Gm || p->Am) // 16-element batches on the fp64 matrix cores, one batch per wavefront
         {
             const size_t lds = (size_t)2 * p->max_loc * sizeof(double);
             const dim3 grid(8 * A.xcd_chunk), block(64);
@@ -1504,7 +1524,8 @@ extern "C"
 #define CUDDH_MFMA_CASE(NB_, NQ_, K_)                                                                              \
     if (!launched && p->nb == NB_ && nq == NQ_ && kind == K_)                                                      \
     {                                                                                                              \
-        hipLaunchKernelGGL((op_mfma_kernel<NB_, NQ_, K_>), grid, block, lds, st, A, accumulate, P, p->DS, p->Gm, p->gm_stride);  \
+        hipLaunchKernelGGL((op_mfma_kernel<NB_, NQ_, K_>), grid, block, lds, st, A, accumulate, P, p->DS, K_ == 0 ? p->Gm : p->Am,  \
+                           K_ == 0 ? p->gm_stride : p->am_stride);  \
         launched = true;                                                                                           \
     }
             CUDDH_MFMA_CASE(6, 7, 0)
