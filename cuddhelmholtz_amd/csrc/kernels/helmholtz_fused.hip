@@ -582,10 +582,13 @@ namespace
             hipLaunchKernelGGL((helm_patch_kernel<NB, NQS, NQM, false, false>), grid, block, lds, st, A, p->PS, p->DS, p->PM, p->PF, p->Gu);
     }
 
+    // fused complex apply on the fp64 matrix cores (16-element batches)
+    bool helm_mfma(int nb, int nqS, int nqM) { return nb >= 6 && nb <= 8 && nqS == nb + 1 && nqM == 2 + 3 * nb / 2; }
+
     bool supported(int nb, int nqS, int nqM)
     {
         return (nb == 3 && nqS == 4 && nqM == 6) || (nb == 4 && nqS == 5 && nqM == 8) || (nb == 5 && nqS == 6 && nqM == 9) ||
-               (nb == 2 && nqS == 3 && nqM == 5) || (nb == 6 && nqS == 7 && nqM == 11);
+               (nb == 2 && nqS == 3 && nqM == 5) || helm_mfma(nb, nqS, nqM);
     }
 
     HelmArgs plan_args(const cuddh_helmholtz_plan *p, const double *x, double *y)
@@ -1093,6 +1096,328 @@ namespace
         }
     }
 
+    // ---------------------------------------------------------------- fused complex Helmholtz apply on the fp64 matrix cores
+    // [u; v] -> [S u - w^2 M u - w H v ; -(S v - w^2 M v + w H u)] for n_basis 6-8 in the scheme of op_mfma_kernel: a batch
+    // of 16 elements per wavefront, both components in the same lanes (the metric slices are loaded once and used for u and
+    // v), stiffness slices then mass slices.  The LDS copy of x is consumed when the registers are filled, so the same LDS
+    // serves as the accumulator y (2 x max_loc doubles per wavefront instead of 4); the boundary-face term re-reads its few
+    // x values from global memory.
+    template <int NB, int NQS, int NQM>
+    __global__ void __launch_bounds__(64, 2) helm_mfma_kernel(HelmArgs A, const double *__restrict__ PS, const double *__restrict__ DS,
+                                                              const double *__restrict__ PM, const double *__restrict__ PF,
+                                                              const double *__restrict__ Gm, long long gm_stride,
+                                                              const double *__restrict__ Am, long long am_stride)
+    {
+        static_assert(NB >= 5 && NB <= 8 && NQS <= 16 && NQM <= 16, "xi-indices k = g + 4 s with s < 2");
+        constexpr int NN = NB * NB, NP = (NN + 1) / 2, PEM = 16;
+        constexpr int JS = (NQS + 3) / 4, JM = (NQM + 3) / 4;
+        extern __shared__ double lds[];
+        const int patch = (blockIdx.x & 7) * A.xcd_chunk + (blockIdx.x >> 3);
+        if (patch >= A.n_patches)
+            return; // whole workgroup
+        const int lane = threadIdx.x, e = lane & 15, g = lane >> 4;
+        const int ML = A.max_loc;
+        double *xy = lds; // [2][ML]: first the gathered x, then the accumulated y
+        const int off = A.dof_off[patch];
+        const int nloc = A.dof_off[patch + 1] - off;
+        const int *dofs = A.dof_list + off;
+        const bool active = e < A.patch_nel[patch];
+        const int mycol = active ? A.colour[patch * PEM + e] : -1;
+        const uint32_t *li = A.lidx + (size_t)patch * NP * PEM + e;
+        int id[2][NB];
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int l = 0; l < NB; ++l)
+            {
+                const int n = g + 4 * s + NB * l;
+                const uint32_t w = (g + 4 * s < NB) ? li[(n >> 1) * PEM] : 0u;
+                id[s][l] = (n & 1) ? static_cast<int>(w >> 16) : static_cast<int>(w & 0xFFFFu);
+            }
+
+        constexpr int ROWS = 7;
+        for (int base = 0; base < nloc; base += 64 * ROWS)
+        {
+            int gi[ROWS];
+#pragma unroll
+            for (int j = 0; j < ROWS; ++j)
+                gi[j] = dofs[min(base + 64 * j + lane, nloc - 1)];
+            double xu[ROWS], xv[ROWS];
+#pragma unroll
+            for (int j = 0; j < ROWS; ++j)
+            {
+                xu[j] = A.x[gi[j]];
+                xv[j] = A.x[A.ndof + gi[j]];
+            }
+#pragma unroll
+            for (int j = 0; j < ROWS; ++j)
+            {
+                const int i = base + 64 * j + lane;
+                if (i < nloc)
+                {
+                    xy[i] = xu[j];
+                    xy[ML + i] = xv[j];
+                }
+            }
+        }
+        __syncthreads();
+        double U[2][2][NB], OUT[2][2][NB]; // [component][s][l]
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int l = 0; l < NB; ++l)
+                {
+                    U[c][s][l] = (active && g + 4 * s < NB) ? xy[c * ML + id[s][l]] : 0.0;
+                    OUT[c][s][l] = 0.0;
+                }
+        __syncthreads();
+        for (int i = lane; i < nloc; i += 64)
+        {
+            xy[i] = 0.0;
+            xy[ML + i] = 0.0;
+        }
+        __syncthreads();
+
+        // ------------------------------------------------------------ stiffness slices
+        {
+            double AfD[2], AfP[2], AbD[JS], AbP[JS];
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+            {
+                const int q = e, kp = 4 * s + g;
+                const bool ok = q < NQS && kp < NB;
+                AfD[s] = ok ? DS[q + NQS * kp] : 0.0;
+                AfP[s] = ok ? PS[q + NQS * kp] : 0.0;
+            }
+#pragma unroll
+            for (int sp = 0; sp < JS; ++sp)
+            {
+                const int k = e, q = 4 * sp + g;
+                const bool ok = k < NB && q < NQS;
+                AbD[sp] = ok ? DS[q + NQS * k] : 0.0;
+                AbP[sp] = ok ? PS[q + NQS * k] : 0.0;
+            }
+            const double *Gb = Gm + (size_t)patch * gm_stride + e;
+#pragma unroll 1
+            for (int r = 0; r < NQS; ++r)
+            {
+                double ga[JS], gb[JS], gc[JS];
+#pragma unroll
+                for (int j = 0; j < JS; ++j)
+                {
+                    const int q = 4 * j + g;
+                    const bool ok = q < NQS;
+                    const size_t o = (((size_t)r * 3) * NQS + (ok ? q : 0)) * PEM;
+                    ga[j] = ok ? __builtin_nontemporal_load(&Gb[o]) : 0.0;
+                    gb[j] = ok ? __builtin_nontemporal_load(&Gb[o + (size_t)NQS * PEM]) : 0.0;
+                    gc[j] = ok ? __builtin_nontemporal_load(&Gb[o + (size_t)2 * NQS * PEM]) : 0.0;
+                }
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+                {
+                    double pl[2], dl[2];
+#pragma unroll
+                    for (int s = 0; s < 2; ++s)
+                    {
+                        double a = 0.0, b = 0.0;
+#pragma unroll
+                        for (int l = 0; l < NB; ++l)
+                        {
+                            a += PS[r + NQS * l] * U[c][s][l];
+                            b += DS[r + NQS * l] * U[c][s][l];
+                        }
+                        pl[s] = a;
+                        dl[s] = b;
+                    }
+                    mfma_d4 dx = {0, 0, 0, 0}, dy = {0, 0, 0, 0};
+#pragma unroll
+                    for (int s = 0; s < 2; ++s)
+                    {
+                        dx = __builtin_amdgcn_mfma_f64_16x16x4f64(AfD[s], pl[s], dx, 0, 0, 0);
+                        dy = __builtin_amdgcn_mfma_f64_16x16x4f64(AfP[s], dl[s], dy, 0, 0, 0);
+                    }
+                    mfma_d4 W0 = {0, 0, 0, 0}, W1 = {0, 0, 0, 0};
+#pragma unroll
+                    for (int j = 0; j < JS; ++j)
+                    {
+                        const double f0 = ga[j] * dx[j] + gb[j] * dy[j];
+                        const double f1 = gb[j] * dx[j] + gc[j] * dy[j];
+                        W0 = __builtin_amdgcn_mfma_f64_16x16x4f64(AbD[j], f0, W0, 0, 0, 0);
+                        W1 = __builtin_amdgcn_mfma_f64_16x16x4f64(AbP[j], f1, W1, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int s = 0; s < 2; ++s)
+#pragma unroll
+                        for (int l = 0; l < NB; ++l)
+                            OUT[c][s][l] += PS[r + NQS * l] * W0[s] + DS[r + NQS * l] * W1[s];
+                }
+            }
+        }
+
+        // ------------------------------------------------------------ mass slices: out -= w^2 M u
+        {
+            const double w2 = -A.omega * A.omega;
+            double AfP[2], AbP[JM];
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+            {
+                const int q = e, kp = 4 * s + g;
+                AfP[s] = (q < NQM && kp < NB) ? PM[q + NQM * kp] : 0.0;
+            }
+#pragma unroll
+            for (int sp = 0; sp < JM; ++sp)
+            {
+                const int k = e, q = 4 * sp + g;
+                AbP[sp] = (k < NB && q < NQM) ? PM[q + NQM * k] : 0.0;
+            }
+            const double *ab = Am + (size_t)patch * am_stride + e;
+#pragma unroll 1
+            for (int r = 0; r < NQM; ++r)
+            {
+                double am[JM];
+#pragma unroll
+                for (int j = 0; j < JM; ++j)
+                {
+                    const int q = 4 * j + g;
+                    am[j] = q < NQM ? w2 * __builtin_nontemporal_load(&ab[((size_t)r * NQM + q) * PEM]) : 0.0;
+                }
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+                {
+                    double pl[2];
+#pragma unroll
+                    for (int s = 0; s < 2; ++s)
+                    {
+                        double a = 0.0;
+#pragma unroll
+                        for (int l = 0; l < NB; ++l)
+                            a += PM[r + NQM * l] * U[c][s][l];
+                        pl[s] = a;
+                    }
+                    mfma_d4 v = {0, 0, 0, 0}, W = {0, 0, 0, 0};
+#pragma unroll
+                    for (int s = 0; s < 2; ++s)
+                        v = __builtin_amdgcn_mfma_f64_16x16x4f64(AfP[s], pl[s], v, 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < JM; ++j)
+                        W = __builtin_amdgcn_mfma_f64_16x16x4f64(AbP[j], am[j] * v[j], W, 0, 0, 0);
+#pragma unroll
+                    for (int s = 0; s < 2; ++s)
+#pragma unroll
+                        for (int l = 0; l < NB; ++l)
+                            OUT[c][s][l] += PM[r + NQM * l] * W[s];
+                }
+            }
+        }
+
+        // ------------------------------------------------------------ accumulate in colour phases; the v row is negated
+        for (int c = 0; c < A.ncol; ++c)
+        {
+            if (mycol == c)
+            {
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+                    if (g + 4 * s < NB)
+                    {
+#pragma unroll
+                        for (int l = 0; l < NB; ++l)
+                        {
+                            xy[id[s][l]] += OUT[0][s][l];
+                            xy[ML + id[s][l]] -= OUT[1][s][l];
+                        }
+                    }
+            }
+            __syncthreads();
+        }
+
+        // ------------------------------------------------------------ boundary faces:  Au -= w H v,  Av -= w H u
+        {
+            const int f_begin = A.face_off[patch], nf = A.face_off[patch + 1] - f_begin;
+            const int comp = lane >> 5, le = lane & 31;
+            const double *xo = A.x + (size_t)(1 - comp) * A.ndof; // the other component, from global memory (few values)
+            double *yc = xy + comp * ML;
+            const int nqF = A.nqF;
+            for (int f0 = 0; f0 < nf; f0 += 32)
+            {
+                const int f = f0 + le;
+                const bool fa = f < nf;
+                double res[NB];
+                int fl[NB];
+                int fc = -1;
+#pragma unroll
+                for (int k = 0; k < NB; ++k)
+                {
+                    res[k] = 0.0;
+                    fl[k] = 0;
+                }
+                if (fa)
+                {
+                    const uint16_t *fli = A.face_lidx + (size_t)(f_begin + f) * NB;
+                    const double *af = A.aF + (size_t)nqF * A.face_id[f_begin + f];
+                    fc = A.face_col[f_begin + f];
+                    double w[NB];
+#pragma unroll
+                    for (int k = 0; k < NB; ++k)
+                    {
+                        fl[k] = fli[k];
+                        w[k] = xo[dofs[fl[k]]];
+                    }
+                    for (int q = 0; q < nqF; ++q)
+                    {
+                        double pv = 0.0;
+#pragma unroll
+                        for (int k = 0; k < NB; ++k)
+                            pv += PF[q + nqF * k] * w[k];
+                        pv *= af[q];
+#pragma unroll
+                        for (int k = 0; k < NB; ++k)
+                            res[k] += PF[q + nqF * k] * pv;
+                    }
+                }
+                for (int c = 0; c < A.nfcol; ++c)
+                {
+                    if (fc == c)
+                    {
+#pragma unroll
+                        for (int k = 0; k < NB; ++k)
+                            yc[fl[k]] -= A.omega * res[k];
+                    }
+                    __syncthreads();
+                }
+            }
+        }
+
+        // ------------------------------------------------------------ write out
+        const int *slot = A.slot_of + off;
+        for (int base = 0; base < nloc; base += 64 * ROWS)
+        {
+            int dest[ROWS];
+#pragma unroll
+            for (int j = 0; j < ROWS; ++j)
+                dest[j] = slot[min(base + 64 * j + lane, nloc - 1)];
+#pragma unroll
+            for (int j = 0; j < ROWS; ++j)
+            {
+                const int i = base + 64 * j + lane;
+                if (i >= nloc)
+                    continue;
+                if (dest[j] >= 0)
+                {
+                    A.y[dest[j]] = xy[i];
+                    A.y[A.ndof + dest[j]] = xy[ML + i];
+                }
+                else
+                {
+                    const int sl = -dest[j] - 1;
+                    A.part[sl] = xy[i];
+                    A.part[A.n_slots + sl] = xy[ML + i];
+                }
+            }
+        }
+    }
+
     __global__ void __launch_bounds__(256) op_border_kernel(int n_shared, int accumulate, const int *__restrict__ shared_dof,
                                                            const int *__restrict__ shared_off,
                                                            const double *__restrict__ part, double *__restrict__ y)
@@ -1490,7 +1815,7 @@ extern "C"
         if (!supported(nb, nqS, nqM) || n_elem <= 0)
             return static_cast<int>(hipErrorNotSupported);
         return build_plan(out, ndof, n_elem, nb, h_I, h_xy, nqS, h_PS, h_DS, G_S, nqM, h_PM, a_M, n_faces, h_fI, h_face_elem, nqF,
-                          h_PF, a_F);
+                          h_PF, a_F, helm_mfma(nb, nqS, nqM) ? 16 : PE);
     }
 
     int cuddh_hip_operator_plan_create(cuddh_helmholtz_plan **out, int kind, int ndof, int n_elem, int nb, const int *h_I,
@@ -1568,14 +1893,26 @@ extern "C"
         HelmArgs A = plan_args(p, x, y);
         A.omega = omega;
 
-        if (p->nb == 4)
+        if (p->Gm && p->Am) // n_basis 6-8: fp64 matrix cores, one 16-element batch per wavefront
+        {
+            const size_t lds = (size_t)2 * p->max_loc * sizeof(double);
+            const dim3 grid(8 * A.xcd_chunk), block(64);
+            if (p->nb == 6)
+                hipLaunchKernelGGL((helm_mfma_kernel<6, 7, 11>), grid, block, lds, st, A, p->PS, p->DS, p->PM, p->PF, p->Gm, p->gm_stride, p->Am,
+                                   p->am_stride);
+            else if (p->nb == 7)
+                hipLaunchKernelGGL((helm_mfma_kernel<7, 8, 12>), grid, block, lds, st, A, p->PS, p->DS, p->PM, p->PF, p->Gm, p->gm_stride, p->Am,
+                                   p->am_stride);
+            else
+                hipLaunchKernelGGL((helm_mfma_kernel<8, 9, 14>), grid, block, lds, st, A, p->PS, p->DS, p->PM, p->PF, p->Gm, p->gm_stride, p->Am,
+                                   p->am_stride);
+        }
+        else if (p->nb == 4)
             launch_patch<4, 5, 8>(p, A, st);
         else if (p->nb == 3)
             launch_patch<3, 4, 6>(p, A, st);
         else if (p->nb == 5)
             launch_patch<5, 6, 9>(p, A, st);
-        else if (p->nb == 6)
-            launch_patch<6, 7, 11>(p, A, st);
         else
             launch_patch<2, 3, 5>(p, A, st);
         int err = launch_status();
