@@ -900,7 +900,7 @@ namespace
                 id[s][l] = (n & 1) ? static_cast<int>(w >> 16) : static_cast<int>(w & 0xFFFFu);
             }
 
-        constexpr int ROWS = 8;
+        constexpr int ROWS = 14; // 896 dofs per pass: a 4x4-element batch of n_basis 8 (841) in one
         for (int base = 0; base < nloc; base += 64 * ROWS)
         {
             int gi[ROWS];
@@ -1135,7 +1135,7 @@ namespace
                 id[s][l] = (n & 1) ? static_cast<int>(w >> 16) : static_cast<int>(w & 0xFFFFu);
             }
 
-        constexpr int ROWS = 7;
+        constexpr int ROWS = 14; // 896 dofs per pass: a 4x4-element batch of n_basis 8 (841) in one
         for (int base = 0; base < nloc; base += 64 * ROWS)
         {
             int gi[ROWS];
