@@ -131,7 +131,7 @@ def test_stiffness_mass_apply(cuda, kind, nb):
     assert rel(z.cpu().numpy(), oracle.diag_inv_mass(d) * xh) < 1e-13
 
 
-@pytest.mark.parametrize("nb", [3, 4])
+@pytest.mark.parametrize("nb", [3, 4, 7])
 def test_operator_plan_and_generic_kernels_agree(cuda, nb, monkeypatch):
     """StiffnessMatrix / MassMatrix pick the patch-plan kernels (cuddh_hip_operator_plan_*) when one exists for
     (n_basis, n_quad) and the generic batched kernels otherwise; CUDDH_OPERATOR_PLAN=0 forces the latter.  Both must
