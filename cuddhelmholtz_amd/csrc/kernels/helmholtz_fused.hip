@@ -1,23 +1,26 @@
-// Fused complex Helmholtz apply  [u;v] -> [S u - w^2 M u - w H v ; -(S v - w^2 M v + w H u)].
+// Plan-based matrix-free operator applies: the fused complex Helmholtz apply
+//     [u;v] -> [S u - w^2 M u - w H v ; -(S v - w^2 M v + w H u)]
+// and the single real operators  y = [y +] c S x,  y = [y +] c M x  behind the same plan.
 //
-// Bandwidth design (MI355X): elements are grouped into PATCHES of 32 (Morton
-// order of their centroids: 4x8 blocks on a structured mesh).  One wavefront
-// owns one patch; lane = (element, component): lanes 0-31 apply the operators to
-// u, lanes 32-63 to v of the same 32 elements, so the metric tensors, the mass
-// weights and the index map are fetched once for both components.
-//   * x of the patch's dofs is gathered once into LDS (x_u, x_v); results are
-//     accumulated in LDS (y_u, y_v) in colour phases (elements of one colour share
-//     no dof), i.e. without atomics and in a fixed order;
-//   * each lane runs the whole sum factorisation of its element in registers;
-//     the 1-D interpolation/differentiation matrices are compile-time-indexed
-//     loads from a uniform pointer (scalar registers);
-//   * metric arrays are stored patch-major, structure-of-arrays
-//     [patch][xi-slice q][component][eta index r][32 lanes]: every load instruction
-//     reads 256 contiguous bytes and the 3*nq (or nq) loads of one slice cover one
-//     contiguous 3.75 KB (2 KB) block, so DRAM pages are read whole;
-//   * dofs owned by one patch are stored straight to y; dofs on patch borders go
-//     to per-patch slots that a second small kernel sums in a fixed order.
-// The apply is therefore bitwise reproducible and needs no zero-fill of y.
+// Kernels in this file
+//   helm_patch_kernel   n_basis 2-5, complex: one element per lane, patches of 32 elements, lanes 0-31 u / 32-63 v
+//   op_patch_kernel     n_basis 2-5, real   : one element per lane, two patches of 32 per wavefront
+//   helm_mfma_kernel    n_basis 6-8, complex: batches of 16 elements, 1-D contractions on v_mfma_f64_16x16x4_f64
+//   op_mfma_kernel      n_basis 6-8, real   : the same for one operator
+//   helm_border_kernel / op_border_kernel: sums of the per-patch contributions at dofs shared by several patches
+//   repack_*, uniform_metric_kernel: plan construction
+//
+// Common design (MI355X): elements are grouped into patches (Morton order of their centroids: 4x8 or 4x4 blocks on a
+// structured mesh); one wavefront owns one patch (or two).
+//   * x of the patch's dofs is gathered once into LDS; results are accumulated in LDS in colour phases (elements of one
+//     colour share no dof), i.e. without atomics and in a fixed order;
+//   * the sum factorisation of an element runs in registers; the 1-D interpolation / differentiation matrices are loads
+//     from a uniform pointer (scalar registers) or MFMA A operands;
+//   * metric arrays are stored patch-major, structure-of-arrays, one contiguous block per quadrature slice, so every load
+//     instruction reads 256-512 contiguous bytes and DRAM pages are read whole; on affine meshes one copy serves all;
+//   * dofs owned by one patch are stored straight to y; dofs on patch borders go to per-patch slots that a second small
+//     kernel sums in a fixed order.
+// Every apply is therefore bitwise reproducible and needs no zero-fill of y.
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
