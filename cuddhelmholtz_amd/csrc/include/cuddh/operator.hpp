@@ -1,32 +1,32 @@
-// Abstract linear operators acting on DEVICE vectors.
-// Contract: reference include/Operator.hpp:6-26.
+// The two abstract operator interfaces every solver in this library is written against.  All vectors are DEVICE
+// pointers.  Contract: reference include/Operator.hpp:6-26 (same class names and virtual signatures, so user
+// operators written for the reference -- e.g. the Poisson and Helmholtz classes of its examples -- derive unchanged).
 #ifndef CUDDH_AMD_OPERATOR_HPP
 #define CUDDH_AMD_OPERATOR_HPP
 
 namespace cuddh
 {
-    /// double precision operator
+    /// fp64 operator; matrix-free operators, preconditioners and user operators derive from it
     class Operator
     {
-    public:
-        Operator() = default;
-        virtual ~Operator() = default;
+    protected:
+        Operator() {}
 
-        /// y <- y + c * A * x
-        virtual void action(double c, const double *x, double *y) const = 0;
-        /// y <- A * x
-        virtual void action(const double *x, double *y) const = 0;
+    public:
+        virtual ~Operator() {}
+        virtual void action(double scale, const double *in, double *accum) const = 0; ///< accum += scale * A in
+        virtual void action(const double *in, double *out) const = 0;                 ///< out = A in (overwrites)
     };
 
-    /// single precision operator (the DDH interface operator works on float traces)
+    /// fp32 operator: DDH acts on float trace vectors (reference include/DDH.hpp:22)
     class SinglePrecisionOperator
     {
-    public:
-        SinglePrecisionOperator() = default;
-        virtual ~SinglePrecisionOperator() = default;
+    protected:
+        SinglePrecisionOperator() {}
 
-        /// y <- A * x
-        virtual void action(const float *x, float *y) const = 0;
+    public:
+        virtual ~SinglePrecisionOperator() {}
+        virtual void action(const float *in, float *out) const = 0; ///< out = A in
     };
 } // namespace cuddh
 
