@@ -939,7 +939,12 @@ namespace
 
         // A operands: row i = lane % 16, column = 4 * step + lane / 16.  forward (rows q, columns k'): D(q, k'), P(q, k');
         // backward (rows k, columns q): D(q, k), P(q, k)
-        double AfD[2], AfP[2], AbD[JQ], AbP[JQ];
+        // backward products run on v_mfma_f64_4x4x4_f64 (four independent 4 x 4 x 4 blocks, one per group of four elements):
+        // same B / C lane layout as the 16 x 16 x 4 form (k-index and output row = lane / 16, column = lane % 16) but only the
+        // KB = ceil(NB / 4) row blocks that exist are computed -- no padding to 16 rows.  A[rb][j]: row 4 rb + (lane & 3),
+        // column 4 j + (lane >> 4).
+        constexpr int KB = (NB + 3) / 4;
+        double AfD[2], AfP[2], AbD[KB][JQ], AbP[KB][JQ];
 #pragma unroll
         for (int s = 0; s < 2; ++s)
         {
@@ -949,13 +954,15 @@ namespace
             AfP[s] = ok ? P[q + NQ * kp] : 0.0;
         }
 #pragma unroll
-        for (int sp = 0; sp < JQ; ++sp)
-        {
-            const int k = e, q = 4 * sp + g;
-            const bool ok = k < NB && q < NQ;
-            AbD[sp] = (KIND == 0 && ok) ? D[q + NQ * k] : 0.0;
-            AbP[sp] = ok ? P[q + NQ * k] : 0.0;
-        }
+        for (int rb = 0; rb < KB; ++rb)
+#pragma unroll
+            for (int sp = 0; sp < JQ; ++sp)
+            {
+                const int k = 4 * rb + (lane & 3), q = 4 * sp + g;
+                const bool ok = k < NB && q < NQ;
+                AbD[rb][sp] = (KIND == 0 && ok) ? D[q + NQ * k] : 0.0;
+                AbP[rb][sp] = ok ? P[q + NQ * k] : 0.0;
+            }
 
         if constexpr (KIND == 0)
         {
@@ -998,14 +1005,21 @@ namespace
                     dy = __builtin_amdgcn_mfma_f64_16x16x4f64(AfP[s], dl[s], dy, 0, 0, 0);
                 }
                 // W0(k) = sum_q D(q, k) F0(q, r),  W1(k) = sum_q P(q, k) F1(q, r)
-                mfma_d4 W0 = {0, 0, 0, 0}, W1 = {0, 0, 0, 0};
+                double W0[KB], W1[KB];
+#pragma unroll
+                for (int rb = 0; rb < KB; ++rb)
+                    W0[rb] = W1[rb] = 0.0;
 #pragma unroll
                 for (int j = 0; j < JQ; ++j)
                 {
                     const double f0 = ga[j] * dx[j] + gb[j] * dy[j];
                     const double f1 = gb[j] * dx[j] + gc[j] * dy[j];
-                    W0 = __builtin_amdgcn_mfma_f64_16x16x4f64(AbD[j], f0, W0, 0, 0, 0);
-                    W1 = __builtin_amdgcn_mfma_f64_16x16x4f64(AbP[j], f1, W1, 0, 0, 0);
+#pragma unroll
+                    for (int rb = 0; rb < KB; ++rb)
+                    {
+                        W0[rb] = __builtin_amdgcn_mfma_f64_4x4x4f64(AbD[rb][j], f0, W0[rb], 0, 0, 0);
+                        W1[rb] = __builtin_amdgcn_mfma_f64_4x4x4f64(AbP[rb][j], f1, W1[rb], 0, 0, 0);
+                    }
                 }
                 // out(k, l) += P(r, l) W0(k) + D(r, l) W1(k),  k = 4 s + g
 #pragma unroll
@@ -1039,13 +1053,19 @@ namespace
                     pl[s] = a;
                 }
                 // v(q, r) = sum_k' P(q, k') pl_k'(r);  W(k) = sum_q P(q, k) a(q, r) v(q, r)
-                mfma_d4 v = {0, 0, 0, 0}, W = {0, 0, 0, 0};
+                mfma_d4 v = {0, 0, 0, 0};
 #pragma unroll
                 for (int s = 0; s < 2; ++s)
                     v = __builtin_amdgcn_mfma_f64_16x16x4f64(AfP[s], pl[s], v, 0, 0, 0);
+                double W[KB];
+#pragma unroll
+                for (int rb = 0; rb < KB; ++rb)
+                    W[rb] = 0.0;
 #pragma unroll
                 for (int j = 0; j < JQ; ++j)
-                    W = __builtin_amdgcn_mfma_f64_16x16x4f64(AbP[j], am[j] * v[j], W, 0, 0, 0);
+#pragma unroll
+                    for (int rb = 0; rb < KB; ++rb)
+                        W[rb] = __builtin_amdgcn_mfma_f64_4x4x4f64(AbP[rb][j], am[j] * v[j], W[rb], 0, 0, 0);
 #pragma unroll
                 for (int s = 0; s < 2; ++s)
 #pragma unroll

@@ -108,6 +108,32 @@ __global__ void __launch_bounds__(64) mfma64_kernel(float *out, int iters, long 
         cycles[blockIdx.x] = t1 - t0;
 }
 
+__global__ void __launch_bounds__(64) mfma64_4x4_kernel(float *out, int iters, long long *cycles)
+{
+    double c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0, c6 = 0, c7 = 0;
+    const double a = 1.0 + 1e-9 * threadIdx.x, b = 1e-6;
+    const long long t0 = clock64();
+    for (int it = 0; it < iters; ++it)
+    {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) // 64 MFMAs per iteration
+        {
+            c0 = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c1, 0, 0, 0);
+            c2 = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c2, 0, 0, 0);
+            c3 = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c3, 0, 0, 0);
+            c4 = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c4, 0, 0, 0);
+            c5 = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c5, 0, 0, 0);
+            c6 = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c6, 0, 0, 0);
+            c7 = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c7, 0, 0, 0);
+        }
+    }
+    const long long t1 = clock64();
+    out[blockIdx.x * 64 + threadIdx.x] = static_cast<float>(c0 + c1 + c2 + c3 + c4 + c5 + c6 + c7);
+    if (threadIdx.x == 0)
+        cycles[blockIdx.x] = t1 - t0;
+}
+
 template <typename K>
 void run(const char *name, K kernel, int waves_per_simd)
 {
@@ -154,6 +180,7 @@ int main()
         run("v_pk_fma_f32", pk_kernel, w);
         run("v_fma_f64", fma64_kernel, w);
         run("v_mfma_f64_16x16x4_f64", mfma64_kernel, w);
+        run("v_mfma_f64_4x4x4_4b_f64", mfma64_4x4_kernel, w);
     }
     return 0;
 }
