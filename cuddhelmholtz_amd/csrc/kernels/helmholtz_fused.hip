@@ -1205,7 +1205,8 @@ namespace
 
         // ------------------------------------------------------------ stiffness slices
         {
-            double AfD[2], AfP[2], AbD[JS], AbP[JS];
+            constexpr int KB = (NB + 3) / 4; // backward products on v_mfma_f64_4x4x4_f64, as in op_mfma_kernel
+            double AfD[2], AfP[2], AbD[KB][JS], AbP[KB][JS];
 #pragma unroll
             for (int s = 0; s < 2; ++s)
             {
@@ -1215,13 +1216,15 @@ namespace
                 AfP[s] = ok ? PS[q + NQS * kp] : 0.0;
             }
 #pragma unroll
-            for (int sp = 0; sp < JS; ++sp)
-            {
-                const int k = e, q = 4 * sp + g;
-                const bool ok = k < NB && q < NQS;
-                AbD[sp] = ok ? DS[q + NQS * k] : 0.0;
-                AbP[sp] = ok ? PS[q + NQS * k] : 0.0;
-            }
+            for (int rb = 0; rb < KB; ++rb)
+#pragma unroll
+                for (int sp = 0; sp < JS; ++sp)
+                {
+                    const int k = 4 * rb + (lane & 3), q = 4 * sp + g;
+                    const bool ok = k < NB && q < NQS;
+                    AbD[rb][sp] = ok ? DS[q + NQS * k] : 0.0;
+                    AbP[rb][sp] = ok ? PS[q + NQS * k] : 0.0;
+                }
             const double *Gb = Gm + (size_t)patch * gm_stride + e;
 #pragma unroll 1
             for (int r = 0; r < NQS; ++r)
@@ -1261,14 +1264,21 @@ namespace
                         dx = __builtin_amdgcn_mfma_f64_16x16x4f64(AfD[s], pl[s], dx, 0, 0, 0);
                         dy = __builtin_amdgcn_mfma_f64_16x16x4f64(AfP[s], dl[s], dy, 0, 0, 0);
                     }
-                    mfma_d4 W0 = {0, 0, 0, 0}, W1 = {0, 0, 0, 0};
+                    double W0[KB], W1[KB];
+#pragma unroll
+                    for (int rb = 0; rb < KB; ++rb)
+                        W0[rb] = W1[rb] = 0.0;
 #pragma unroll
                     for (int j = 0; j < JS; ++j)
                     {
                         const double f0 = ga[j] * dx[j] + gb[j] * dy[j];
                         const double f1 = gb[j] * dx[j] + gc[j] * dy[j];
-                        W0 = __builtin_amdgcn_mfma_f64_16x16x4f64(AbD[j], f0, W0, 0, 0, 0);
-                        W1 = __builtin_amdgcn_mfma_f64_16x16x4f64(AbP[j], f1, W1, 0, 0, 0);
+#pragma unroll
+                        for (int rb = 0; rb < KB; ++rb)
+                        {
+                            W0[rb] = __builtin_amdgcn_mfma_f64_4x4x4f64(AbD[rb][j], f0, W0[rb], 0, 0, 0);
+                            W1[rb] = __builtin_amdgcn_mfma_f64_4x4x4f64(AbP[rb][j], f1, W1[rb], 0, 0, 0);
+                        }
                     }
 #pragma unroll
                     for (int s = 0; s < 2; ++s)
@@ -1282,7 +1292,8 @@ namespace
         // ------------------------------------------------------------ mass slices: out -= w^2 M u
         {
             const double w2 = -A.omega * A.omega;
-            double AfP[2], AbP[JM];
+            constexpr int KB = (NB + 3) / 4;
+            double AfP[2], AbP[KB][JM];
 #pragma unroll
             for (int s = 0; s < 2; ++s)
             {
@@ -1290,11 +1301,13 @@ namespace
                 AfP[s] = (q < NQM && kp < NB) ? PM[q + NQM * kp] : 0.0;
             }
 #pragma unroll
-            for (int sp = 0; sp < JM; ++sp)
-            {
-                const int k = e, q = 4 * sp + g;
-                AbP[sp] = (k < NB && q < NQM) ? PM[q + NQM * k] : 0.0;
-            }
+            for (int rb = 0; rb < KB; ++rb)
+#pragma unroll
+                for (int sp = 0; sp < JM; ++sp)
+                {
+                    const int k = 4 * rb + (lane & 3), q = 4 * sp + g;
+                    AbP[rb][sp] = (k < NB && q < NQM) ? PM[q + NQM * k] : 0.0;
+                }
             const double *ab = Am + (size_t)patch * am_stride + e;
 #pragma unroll 1
             for (int r = 0; r < NQM; ++r)
@@ -1319,13 +1332,19 @@ namespace
                             a += PM[r + NQM * l] * U[c][s][l];
                         pl[s] = a;
                     }
-                    mfma_d4 v = {0, 0, 0, 0}, W = {0, 0, 0, 0};
+                    mfma_d4 v = {0, 0, 0, 0};
 #pragma unroll
                     for (int s = 0; s < 2; ++s)
                         v = __builtin_amdgcn_mfma_f64_16x16x4f64(AfP[s], pl[s], v, 0, 0, 0);
+                    double W[KB];
+#pragma unroll
+                    for (int rb = 0; rb < KB; ++rb)
+                        W[rb] = 0.0;
 #pragma unroll
                     for (int j = 0; j < JM; ++j)
-                        W = __builtin_amdgcn_mfma_f64_16x16x4f64(AbP[j], am[j] * v[j], W, 0, 0, 0);
+#pragma unroll
+                        for (int rb = 0; rb < KB; ++rb)
+                            W[rb] = __builtin_amdgcn_mfma_f64_4x4x4f64(AbP[rb][j], am[j] * v[j], W[rb], 0, 0, 0);
 #pragma unroll
                     for (int s = 0; s < 2; ++s)
 #pragma unroll
