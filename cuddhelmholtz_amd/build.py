@@ -102,7 +102,7 @@ def build_examples(verbose: bool = False) -> list[Path]:
     reference tree is present, the reference's own examples/{DDH,Poisson,Helmholtz}.cpp UNCHANGED (drop-in check).
     Binaries go to build/examples/ (git-ignored, shipped to the GPU box)."""
     EXAMPLES_DIR.mkdir(parents=True, exist_ok=True)
-    jobs = [(CSRC / "examples" / "ddh_solve.cpp", "ddh_solve")]
+    jobs = [(CSRC / "examples" / "ddh_solve.cpp", "ddh_solve"), (CSRC / "examples" / "helmholtz_solve.cpp", "helmholtz_solve")]
     if REFERENCE_EXAMPLES.exists():
         jobs += [(REFERENCE_EXAMPLES / f"{n}.cpp", f"{n}_reference_driver") for n in ("DDH", "Poisson", "Helmholtz")]
     outs = []

@@ -121,3 +121,40 @@ def test_reference_poisson_example_runs_unchanged(cuda, tmp_path):
     uo += G
     assert info["success"] and f"After {info['num_iter']} iterations" in r.stdout
     assert np.linalg.norm(u - uo) <= 1e-9 * np.linalg.norm(uo)
+
+
+def test_helmholtz_solve_driver(cuda, tmp_path):
+    """BASELINE config 2 in miniature: the native helmholtz_solve driver (unpreconditioned GMRES(20) on the fused complex
+    apply) against the same pipeline driven from Python through the C handle layer."""
+    import torch
+
+    import cuddhelmholtz_amd as cd
+
+    exe = EX / "helmholtz_solve"
+    if not exe.exists():
+        pytest.fail("build/examples/helmholtz_solve missing: run __graft_entry__.build()")
+    nx, nb, w_over_pi, m, maxit = 48, 4, 3.0, 20, 6
+    (tmp_path / "sol").mkdir()
+    r = subprocess.run([str(exe), str(nx), str(nb), str(w_over_pi), str(m), str(maxit), "0", str(tmp_path / "sol")], capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0, r.stderr
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("helmholtz_solve")][-1]
+    assert "fused=1" in line
+    nmv = int(re.search(r"num_matvec=(\d+)", line).group(1))
+    U_cpp = np.fromfile(tmp_path / "sol" / "helmholtz.0000")
+
+    omega = math.pi * w_over_pi
+    mesh = cd.Mesh2D.uniform_rect(nx, -1.0, 1.0, nx, -1.0, 1.0)
+    fem = cd.H1Space(mesh, cd.Basis(nb))
+    fs = cd.FaceSpace(fem, mesh.boundary_edges())
+    n = fem.size()
+    a2 = torch.zeros(n, dtype=torch.float64, device=cuda)
+    cd.nodal_values(fem, cd.ALPHA_DISK_SQ, a2)
+    A = cd.HelmholtzOperator(omega, a2, torch.ones(fs.size(), dtype=torch.float64, device=cuda), fem, fs)
+    b = torch.zeros(2 * n, dtype=torch.float64, device=cuda)
+    cd.linear_functional(fem, cd.GAUSSIANS, b[:n], param=omega)
+    x = torch.zeros_like(b)
+    out = cd.gmres(2 * n, x, A, b, m, maxit, 0.0)
+    assert out.num_matvec == nmv == 1 + (maxit - 1) * (m + 1)
+    assert np.linalg.norm(U_cpp - x.cpu().numpy()) <= 1e-10 * np.linalg.norm(U_cpp)
+    assert out.res_norm[-1] < out.res_norm[0]
