@@ -1126,7 +1126,7 @@ namespace
     // serves as the accumulator y (2 x max_loc doubles per wavefront instead of 4); the boundary-face term re-reads its few
     // x values from global memory.
     template <int NB, int NQS, int NQM>
-    __global__ void __launch_bounds__(64, 2) helm_mfma_kernel(HelmArgs A, const double *__restrict__ PS, const double *__restrict__ DS,
+    __global__ void __launch_bounds__(64, (NB == 6 ? 3 : 2)) helm_mfma_kernel(HelmArgs A, const double *__restrict__ PS, const double *__restrict__ DS,
                                                               const double *__restrict__ PM, const double *__restrict__ PF,
                                                               const double *__restrict__ Gm, long long gm_stride,
                                                               const double *__restrict__ Am, long long am_stride)
