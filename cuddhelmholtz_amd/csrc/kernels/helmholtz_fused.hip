@@ -1121,24 +1121,27 @@ namespace
 
     // ---------------------------------------------------------------- fused complex Helmholtz apply on the fp64 matrix cores
     // [u; v] -> [S u - w^2 M u - w H v ; -(S v - w^2 M v + w H u)] for n_basis 6-8 in the scheme of op_mfma_kernel: a batch
-    // of 16 elements per wavefront, both components in the same lanes (the metric slices are loaded once and used for u and
-    // v), stiffness slices then mass slices.  The LDS copy of x is consumed when the registers are filled, so the same LDS
-    // serves as the accumulator y (2 x max_loc doubles per wavefront instead of 4); the boundary-face term re-reads its few
-    // x values from global memory.
+    // of 16 elements per WORKGROUP of two wavefronts, wave 0 applying the operators to u and wave 1 to v (stiffness slices,
+    // then mass slices).  Each wave needs the registers of a single-operator kernel only (3-4 waves per SIMD; with both
+    // components in one wave it was 2) and a batch is finished in about half the time: 263 -> 184 us (n_basis 7) and
+    // 364 -> 256 us (n_basis 8) at 147k elements.  Both waves read the same metric slices, so those use the default cache
+    // policy (the second read hits).  The LDS copy of x is consumed when the registers are filled, so the same LDS serves as
+    // the accumulator y (2 x max_loc doubles per batch); the boundary-face term re-reads its few x values from global memory.
     template <int NB, int NQS, int NQM>
-    __global__ void __launch_bounds__(64, (NB == 6 ? 3 : 2)) helm_mfma_kernel(HelmArgs A, const double *__restrict__ PS, const double *__restrict__ DS,
+    __global__ void __launch_bounds__(128, (NB <= 6 ? 4 : 3)) helm_mfma_kernel(HelmArgs A, const double *__restrict__ PS, const double *__restrict__ DS,
                                                               const double *__restrict__ PM, const double *__restrict__ PF,
                                                               const double *__restrict__ Gm, long long gm_stride,
                                                               const double *__restrict__ Am, long long am_stride)
     {
-        static_assert(NB >= 5 && NB <= 8 && NQS <= 16 && NQM <= 16, "xi-indices k = g + 4 s with s < 2");
+        static_assert(NB >= 6 && NB <= 8 && NQS <= 16 && NQM <= 16, "xi-indices k = g + 4 s with s < 2");
         constexpr int NN = NB * NB, NP = (NN + 1) / 2, PEM = 16;
         constexpr int JS = (NQS + 3) / 4, JM = (NQM + 3) / 4;
         extern __shared__ double lds[];
         const int patch = (blockIdx.x & 7) * A.xcd_chunk + (blockIdx.x >> 3);
         if (patch >= A.n_patches)
             return; // whole workgroup
-        const int lane = threadIdx.x, e = lane & 15, g = lane >> 4;
+        const int lane = threadIdx.x & 63, e = lane & 15, g = lane >> 4;
+        const int cmp = threadIdx.x >> 6; // component of this wavefront
         const int ML = A.max_loc;
         double *xy = lds; // [2][ML]: first the gathered x, then the accumulated y
         const int off = A.dof_off[patch];
@@ -1158,13 +1161,13 @@ namespace
                 id[s][l] = (n & 1) ? static_cast<int>(w >> 16) : static_cast<int>(w & 0xFFFFu);
             }
 
-        constexpr int ROWS = 14; // 896 dofs per pass: a 4x4-element batch of n_basis 8 (841) in one
-        for (int base = 0; base < nloc; base += 64 * ROWS)
+        constexpr int ROWS = 7; // 128 threads x 7 = 896 dofs per pass: a 4x4-element batch of n_basis 8 (841) in one
+        for (int base = 0; base < nloc; base += 128 * ROWS)
         {
             int gi[ROWS];
 #pragma unroll
             for (int j = 0; j < ROWS; ++j)
-                gi[j] = dofs[min(base + 64 * j + lane, nloc - 1)];
+                gi[j] = dofs[min(base + 128 * j + (int)threadIdx.x, nloc - 1)];
             double xu[ROWS], xv[ROWS];
 #pragma unroll
             for (int j = 0; j < ROWS; ++j)
@@ -1175,7 +1178,7 @@ namespace
 #pragma unroll
             for (int j = 0; j < ROWS; ++j)
             {
-                const int i = base + 64 * j + lane;
+                const int i = base + 128 * j + (int)threadIdx.x;
                 if (i < nloc)
                 {
                     xy[i] = xu[j];
@@ -1184,19 +1187,17 @@ namespace
             }
         }
         __syncthreads();
-        double U[2][2][NB], OUT[2][2][NB]; // [component][s][l]
+        double U[1][2][NB], OUT[1][2][NB]; // [this wave's component][s][l]
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
+        for (int s = 0; s < 2; ++s)
 #pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int l = 0; l < NB; ++l)
-                {
-                    U[c][s][l] = (active && g + 4 * s < NB) ? xy[c * ML + id[s][l]] : 0.0;
-                    OUT[c][s][l] = 0.0;
-                }
+            for (int l = 0; l < NB; ++l)
+            {
+                U[0][s][l] = (active && g + 4 * s < NB) ? xy[cmp * ML + id[s][l]] : 0.0;
+                OUT[0][s][l] = 0.0;
+            }
         __syncthreads();
-        for (int i = lane; i < nloc; i += 64)
+        for (int i = threadIdx.x; i < nloc; i += 128)
         {
             xy[i] = 0.0;
             xy[ML + i] = 0.0;
@@ -1236,12 +1237,12 @@ namespace
                     const int q = 4 * j + g;
                     const bool ok = q < NQS;
                     const size_t o = (((size_t)r * 3) * NQS + (ok ? q : 0)) * PEM;
-                    ga[j] = ok ? __builtin_nontemporal_load(&Gb[o]) : 0.0;
-                    gb[j] = ok ? __builtin_nontemporal_load(&Gb[o + (size_t)NQS * PEM]) : 0.0;
-                    gc[j] = ok ? __builtin_nontemporal_load(&Gb[o + (size_t)2 * NQS * PEM]) : 0.0;
+                    ga[j] = ok ? Gb[o] : 0.0;
+                    gb[j] = ok ? Gb[o + (size_t)NQS * PEM] : 0.0;
+                    gc[j] = ok ? Gb[o + (size_t)2 * NQS * PEM] : 0.0;
                 }
 #pragma unroll
-                for (int c = 0; c < 2; ++c)
+                for (int c = 0; c < 1; ++c)
                 {
                     double pl[2], dl[2];
 #pragma unroll
@@ -1317,10 +1318,10 @@ namespace
                 for (int j = 0; j < JM; ++j)
                 {
                     const int q = 4 * j + g;
-                    am[j] = q < NQM ? w2 * __builtin_nontemporal_load(&ab[((size_t)r * NQM + q) * PEM]) : 0.0;
+                    am[j] = q < NQM ? w2 * ab[((size_t)r * NQM + q) * PEM] : 0.0;
                 }
 #pragma unroll
-                for (int c = 0; c < 2; ++c)
+                for (int c = 0; c < 1; ++c)
                 {
                     double pl[2];
 #pragma unroll
@@ -1365,10 +1366,7 @@ namespace
                     {
 #pragma unroll
                         for (int l = 0; l < NB; ++l)
-                        {
-                            xy[id[s][l]] += OUT[0][s][l];
-                            xy[ML + id[s][l]] -= OUT[1][s][l];
-                        }
+                            xy[cmp * ML + id[s][l]] += (cmp ? -OUT[0][s][l] : OUT[0][s][l]);
                     }
             }
             __syncthreads();
@@ -1377,11 +1375,11 @@ namespace
         // ------------------------------------------------------------ boundary faces:  Au -= w H v,  Av -= w H u
         {
             const int f_begin = A.face_off[patch], nf = A.face_off[patch + 1] - f_begin;
-            const int comp = lane >> 5, le = lane & 31;
+            const int comp = cmp, le = lane;
             const double *xo = A.x + (size_t)(1 - comp) * A.ndof; // the other component, from global memory (few values)
             double *yc = xy + comp * ML;
             const int nqF = A.nqF;
-            for (int f0 = 0; f0 < nf; f0 += 32)
+            for (int f0 = 0; f0 < nf; f0 += 64)
             {
                 const int f = f0 + le;
                 const bool fa = f < nf;
@@ -1433,29 +1431,23 @@ namespace
 
         // ------------------------------------------------------------ write out
         const int *slot = A.slot_of + off;
-        for (int base = 0; base < nloc; base += 64 * ROWS)
+        constexpr int WROWS = 14;
+        for (int base = 0; base < nloc; base += 64 * WROWS)
         {
-            int dest[ROWS];
+            int dest[WROWS];
 #pragma unroll
-            for (int j = 0; j < ROWS; ++j)
+            for (int j = 0; j < WROWS; ++j)
                 dest[j] = slot[min(base + 64 * j + lane, nloc - 1)];
 #pragma unroll
-            for (int j = 0; j < ROWS; ++j)
+            for (int j = 0; j < WROWS; ++j)
             {
                 const int i = base + 64 * j + lane;
                 if (i >= nloc)
                     continue;
                 if (dest[j] >= 0)
-                {
-                    A.y[dest[j]] = xy[i];
-                    A.y[A.ndof + dest[j]] = xy[ML + i];
-                }
+                    A.y[(size_t)cmp * A.ndof + dest[j]] = xy[cmp * ML + i];
                 else
-                {
-                    const int sl = -dest[j] - 1;
-                    A.part[sl] = xy[i];
-                    A.part[A.n_slots + sl] = xy[ML + i];
-                }
+                    A.part[(size_t)cmp * A.n_slots + (-dest[j] - 1)] = xy[cmp * ML + i];
             }
         }
     }
@@ -1935,10 +1927,10 @@ extern "C"
         HelmArgs A = plan_args(p, x, y);
         A.omega = omega;
 
-        if (p->Gm && p->Am) // n_basis 6-8: fp64 matrix cores, one 16-element batch per wavefront
+        if (p->Gm && p->Am) // n_basis 6-8: fp64 matrix cores, one 16-element batch per workgroup
         {
             const size_t lds = (size_t)2 * p->max_loc * sizeof(double);
-            const dim3 grid(8 * A.xcd_chunk), block(64);
+            const dim3 grid(8 * A.xcd_chunk), block(128); // one wavefront per component
             if (p->nb == 6)
                 hipLaunchKernelGGL((helm_mfma_kernel<6, 7, 11>), grid, block, lds, st, A, p->PS, p->DS, p->PM, p->PF, p->Gm, p->gm_stride, p->Am,
                                    p->am_stride);
