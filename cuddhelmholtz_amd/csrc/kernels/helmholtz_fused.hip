@@ -3,7 +3,8 @@
 // and the single real operators  y = [y +] c S x,  y = [y +] c M x  behind the same plan.
 //
 // Kernels in this file
-//   helm_patch_kernel   n_basis 2-5, complex: one element per lane, patches of 32 elements, lanes 0-31 u / 32-63 v
+//   helm_patch_kernel   n_basis 2-5, complex: one element per lane, lanes 0-31 u / 32-63 v; patches of 32 elements (one
+//                       wavefront) or, for affine plans, 64 (two wavefronts sharing the LDS copy)
 //   op_patch_kernel     n_basis 2-5, real   : one element per lane, two patches of 32 per wavefront
 //   helm_mfma_kernel    n_basis 6-8, complex: batches of 16 elements, 1-D contractions on v_mfma_f64_16x16x4_f64
 //   op_mfma_kernel      n_basis 6-8, real   : the same for one operator
@@ -100,8 +101,9 @@ namespace
     // Variants measured and dropped: software-pipelined slice loads, slices split between the half-waves
     // and exchanged with ds_bpermute, three role-specialised wavefronts per patch, touch-prefetch of the metric block.
     // UG: the stiffness metric is the same in every element and comes from the uniform table GU (scalar loads)
-    template <int NB, int NQS, int NQM, bool NT, bool UG>
-    __global__ void __launch_bounds__(64, (NB >= 5 ? 2 : ((NB == 4 && !UG) ? 3 : 4))) helm_patch_kernel(HelmArgs A, const double *__restrict__ PS, const double *__restrict__ DS,
+    // PEK elements per patch: 32 = one wavefront, 64 = two wavefronts sharing the LDS copy of a larger patch (fewer border dofs)
+    template <int NB, int NQS, int NQM, bool NT, bool UG, int PEK>
+    __global__ void __launch_bounds__(2 * PEK, (NB >= 5 ? 2 : ((NB == 4 && !UG) ? 3 : 4))) helm_patch_kernel(HelmArgs A, const double *__restrict__ PS, const double *__restrict__ DS,
                                                            const double *__restrict__ PM, const double *__restrict__ PF,
                                                            const double *__restrict__ GU)
     {
@@ -112,8 +114,10 @@ namespace
         const int patch = (blockIdx.x & 7) * A.xcd_chunk + (blockIdx.x >> 3);
         if (patch >= A.n_patches)
             return; // whole workgroup
+        constexpr int NTH = 2 * PEK;
         const int lane = threadIdx.x;
-        const int comp = lane >> 5, le = lane & 31;
+        // every wavefront holds 32 elements, u in lanes 0-31 and v in lanes 32-63, so that a metric value is loaded once
+        const int comp = (lane >> 5) & 1, le = (lane & 31) + 32 * (lane >> 6);
         const int ML = A.max_loc;
         double *xs = lds;          // [2][ML]
         double *ys = lds + 2 * ML; // [2][ML]
@@ -122,22 +126,22 @@ namespace
         const int nloc = A.dof_off[patch + 1] - off;
         const int *dofs = A.dof_list + off;
 
-        const double *Gp = A.Gp + (size_t)patch * 3 * NQS * NQS * PE + le;
-        const double *ap = A.aMp + (size_t)patch * NQM * NQM * PE + le;
+        const double *Gp = A.Gp + (size_t)patch * 3 * NQS * NQS * PEK + le;
+        const double *ap = A.aMp + (size_t)patch * NQM * NQM * PEK + le;
 
         // A wavefront's life is a chain of dependent memory round trips (about 2 us each under load); everything that does
         // not depend on the LDS copy of x is therefore requested up front: the element -> local-dof map, the colours, the
         // first metric slice, and the dof indices of the whole patch (384 per pass) before any x value.
         const bool active = le < A.patch_nel[patch];
         constexpr int NP = (NN + 1) / 2;
-        const uint32_t *li = A.lidx + ((size_t)patch * NP) * PE + le;
+        const uint32_t *li = A.lidx + ((size_t)patch * NP) * PEK + le;
         // element node -> patch-local dof, two 16-bit indices per register, kept for the gather here and the
         // scatter below (lidx is padded to 32 lanes per patch, so inactive lanes read valid zeros)
         uint32_t lpk[NP];
 #pragma unroll
         for (int j = 0; j < NP; ++j)
-            lpk[j] = li[j * PE];
-        const int mycol = active ? A.colour[patch * PE + le] : -1;
+            lpk[j] = li[j * PEK];
+        const int mycol = active ? A.colour[patch * PEK + le] : -1;
         // n_basis 4, general layout: 153 VGPRs at 3 waves/SIMD (no spills, first slice prefetched) measured faster than
         // 128 VGPRs with 8 spilled at 4 waves/SIMD (1024^2: 402 vs 420 us; irregular 0.49 M quads: 187 vs 222 us)
         constexpr bool PRE = !UG && NB <= 4;
@@ -147,13 +151,13 @@ namespace
 #pragma unroll
             for (int r = 0; r < NQS; ++r)
             {
-                g_first[3 * r + 0] = metric_load<NT>(&Gp[((0 * 3 + 0) * NQS + r) * PE]);
-                g_first[3 * r + 1] = metric_load<NT>(&Gp[((0 * 3 + 1) * NQS + r) * PE]);
-                g_first[3 * r + 2] = metric_load<NT>(&Gp[((0 * 3 + 2) * NQS + r) * PE]);
+                g_first[3 * r + 0] = metric_load<NT>(&Gp[((0 * 3 + 0) * NQS + r) * PEK]);
+                g_first[3 * r + 1] = metric_load<NT>(&Gp[((0 * 3 + 1) * NQS + r) * PEK]);
+                g_first[3 * r + 2] = metric_load<NT>(&Gp[((0 * 3 + 2) * NQS + r) * PEK]);
             }
         }
 
-        constexpr int ROWS = 6; // 64-lane rows per pass: 384 dofs cover a 4x8-element patch of n_basis 4 (325) in one pass
+        constexpr int ROWS = PEK == 32 ? 6 : 5; // rows of NTH dofs per pass: 384 cover a 4x8-element patch of n_basis 4 (325), 640 an 8x8 one (625)
         // where the results of the first pass of the write-out go: requested here, with everything else that is independent
         // of the element phase, when the registers allow (EARLY), otherwise just before the colour phases
         constexpr bool EARLY = !UG && NB == 4;
@@ -163,14 +167,14 @@ namespace
         {
 #pragma unroll
             for (int j = 0; j < ROWS; ++j)
-                dest0[j] = slot[min(64 * j + lane, nloc - 1)];
+                dest0[j] = slot[min(NTH * j + lane, nloc - 1)];
         }
-        for (int base = 0; base < nloc; base += 64 * ROWS)
+        for (int base = 0; base < nloc; base += NTH * ROWS)
         {
             int gi[ROWS];
 #pragma unroll
             for (int j = 0; j < ROWS; ++j)
-                gi[j] = dofs[min(base + 64 * j + lane, nloc - 1)];
+                gi[j] = dofs[min(base + NTH * j + lane, nloc - 1)];
             double xu[ROWS], xv[ROWS];
 #pragma unroll
             for (int j = 0; j < ROWS; ++j)
@@ -181,7 +185,7 @@ namespace
 #pragma unroll
             for (int j = 0; j < ROWS; ++j)
             {
-                const int i = base + 64 * j + lane;
+                const int i = base + NTH * j + lane;
                 if (i < nloc)
                 {
                     xs[i] = xu[j];
@@ -220,9 +224,9 @@ namespace
                 }
                 else
                 {
-                    g[3 * r + 0] = metric_load<NT>(&Gp[((q * 3 + 0) * NQS + r) * PE]);
-                    g[3 * r + 1] = metric_load<NT>(&Gp[((q * 3 + 1) * NQS + r) * PE]);
-                    g[3 * r + 2] = metric_load<NT>(&Gp[((q * 3 + 2) * NQS + r) * PE]);
+                    g[3 * r + 0] = metric_load<NT>(&Gp[((q * 3 + 0) * NQS + r) * PEK]);
+                    g[3 * r + 1] = metric_load<NT>(&Gp[((q * 3 + 1) * NQS + r) * PEK]);
+                    g[3 * r + 2] = metric_load<NT>(&Gp[((q * 3 + 2) * NQS + r) * PEK]);
                 }
             }
         };
@@ -277,7 +281,7 @@ namespace
         {
 #pragma unroll
             for (int r = 0; r < NQM; ++r)
-                a[r] = metric_load<NT>(&ap[(q * NQM + r) * PE]);
+                a[r] = metric_load<NT>(&ap[(q * NQM + r) * PEK]);
         };
         auto mass_slice = [&](int q, const double (&am)[NQM])
         {
@@ -335,7 +339,7 @@ namespace
         {
 #pragma unroll
             for (int j = 0; j < ROWS; ++j)
-                dest0[j] = slot[min(64 * j + lane, nloc - 1)];
+                dest0[j] = slot[min(NTH * j + lane, nloc - 1)];
         }
 
         // accumulate: elements of one colour touch disjoint dofs
@@ -360,7 +364,7 @@ namespace
             const double *xo = xs + (1 - comp) * ML; // the other component
             double *yc = ys + comp * ML;
             const int nqF = A.nqF;
-            for (int f0 = 0; f0 < nf; f0 += PE)
+            for (int f0 = 0; f0 < nf; f0 += PEK)
             {
                 const int f = f0 + le;
                 const bool fa = f < nf;
@@ -411,16 +415,16 @@ namespace
         }
 
         // ------------------------------------------------------------ write out
-        for (int base = 0; base < nloc; base += 64 * ROWS)
+        for (int base = 0; base < nloc; base += NTH * ROWS)
         {
             int dest[ROWS]; // one index per dof: global dof (owned) or -(slot) - 1 (border)
 #pragma unroll
             for (int j = 0; j < ROWS; ++j)
-                dest[j] = base == 0 ? dest0[j] : slot[min(base + 64 * j + lane, nloc - 1)];
+                dest[j] = base == 0 ? dest0[j] : slot[min(base + NTH * j + lane, nloc - 1)];
 #pragma unroll
             for (int j = 0; j < ROWS; ++j)
             {
-                const int i = base + 64 * j + lane;
+                const int i = base + NTH * j + lane;
                 if (i >= nloc)
                     continue;
                 if (dest[j] >= 0)
@@ -536,20 +540,20 @@ namespace
     }
 
     // reference layout (c, q, r, el) -> [patch][q][c][r][32]
-    __global__ void __launch_bounds__(256) repack_kernel(long long total, int comps, int nq, const int *__restrict__ perm,
+    __global__ void __launch_bounds__(256) repack_kernel(long long total, int comps, int nq, int pe, const int *__restrict__ perm,
                                                         const double *__restrict__ src, double *__restrict__ dst)
     {
         for (long long t = blockIdx.x * 256LL + threadIdx.x; t < total; t += gridDim.x * 256LL)
         {
-            const int le = static_cast<int>(t % PE);
-            long long rest = t / PE;
+            const int le = static_cast<int>(t % pe);
+            long long rest = t / pe;
             const int r = static_cast<int>(rest % nq);
             rest /= nq;
             const int c = static_cast<int>(rest % comps);
             rest /= comps;
             const int q = static_cast<int>(rest % nq);
             const long long patch = rest / nq;
-            const int el = perm[patch * PE + le];
+            const int el = perm[patch * pe + le];
             dst[t] = el >= 0 ? src[c + (size_t)comps * ((q + (size_t)nq * r) + (size_t)nq * nq * el)] : 0.0;
         }
     }
@@ -570,19 +574,28 @@ namespace
         return v;
     }
 
+    template <int NB, int NQS, int NQM, int PEK>
+    void launch_patch_pe(const cuddh_helmholtz_plan *p, const HelmArgs &A, hipStream_t st)
+    {
+        const size_t lds = (size_t)4 * p->max_loc * sizeof(double);
+        const dim3 grid(8 * A.xcd_chunk), block(2 * PEK);
+        if (p->Gu && p->streaming)
+            hipLaunchKernelGGL((helm_patch_kernel<NB, NQS, NQM, true, true, PEK>), grid, block, lds, st, A, p->PS, p->DS, p->PM, p->PF, p->Gu);
+        else if (p->Gu)
+            hipLaunchKernelGGL((helm_patch_kernel<NB, NQS, NQM, false, true, PEK>), grid, block, lds, st, A, p->PS, p->DS, p->PM, p->PF, p->Gu);
+        else if (p->streaming)
+            hipLaunchKernelGGL((helm_patch_kernel<NB, NQS, NQM, true, false, PEK>), grid, block, lds, st, A, p->PS, p->DS, p->PM, p->PF, p->Gu);
+        else
+            hipLaunchKernelGGL((helm_patch_kernel<NB, NQS, NQM, false, false, PEK>), grid, block, lds, st, A, p->PS, p->DS, p->PM, p->PF, p->Gu);
+    }
+
     template <int NB, int NQS, int NQM>
     void launch_patch(const cuddh_helmholtz_plan *p, const HelmArgs &A, hipStream_t st)
     {
-        const size_t lds = (size_t)4 * p->max_loc * sizeof(double);
-        const dim3 grid(8 * A.xcd_chunk), block(64);
-        if (p->Gu && p->streaming)
-            hipLaunchKernelGGL((helm_patch_kernel<NB, NQS, NQM, true, true>), grid, block, lds, st, A, p->PS, p->DS, p->PM, p->PF, p->Gu);
-        else if (p->Gu)
-            hipLaunchKernelGGL((helm_patch_kernel<NB, NQS, NQM, false, true>), grid, block, lds, st, A, p->PS, p->DS, p->PM, p->PF, p->Gu);
-        else if (p->streaming)
-            hipLaunchKernelGGL((helm_patch_kernel<NB, NQS, NQM, true, false>), grid, block, lds, st, A, p->PS, p->DS, p->PM, p->PF, p->Gu);
+        if (p->pe == 64)
+            launch_patch_pe<NB, NQS, NQM, 64>(p, A, st);
         else
-            hipLaunchKernelGGL((helm_patch_kernel<NB, NQS, NQM, false, false>), grid, block, lds, st, A, p->PS, p->DS, p->PM, p->PF, p->Gu);
+            launch_patch_pe<NB, NQS, NQM, 32>(p, A, st);
     }
 
     // fused complex apply on the fp64 matrix cores (16-element batches)
@@ -1549,7 +1562,7 @@ extern "C"
                           int pe = PE)
     {
         *out = nullptr;
-        const bool mfma = pe != PE; // 16-element batches: the matrix-core stiffness kernel
+        const bool mfma = pe == 16; // 16-element batches: the matrix-core kernels
 
         cuddh_helmholtz_plan *p = new cuddh_helmholtz_plan;
         p->ndof = ndof;
@@ -1795,12 +1808,12 @@ extern "C"
                 hipLaunchKernelGGL(repack_mfma_kernel, dim3(stream_grid(nG, 256)), dim3(256), 0, nullptr, nG, 3, nqS, uniform_G ? d_zero : d_perm, G_S,
                                    p->Gm);
             else if (nG > 0)
-                hipLaunchKernelGGL(repack_kernel, dim3(stream_grid(nG, 256)), dim3(256), 0, nullptr, nG, 3, nqS, d_perm, G_S, p->Gp);
+                hipLaunchKernelGGL(repack_kernel, dim3(stream_grid(nG, 256)), dim3(256), 0, nullptr, nG, 3, nqS, pe, d_perm, G_S, p->Gp);
             if (nA > 0 && mfma)
                 hipLaunchKernelGGL(repack_mfma_kernel, dim3(stream_grid(nA, 256)), dim3(256), 0, nullptr, nA, 1, nqM, uniform_a ? d_zero : d_perm, a_M,
                                    p->Am);
             else if (nA > 0)
-                hipLaunchKernelGGL(repack_kernel, dim3(stream_grid(nA, 256)), dim3(256), 0, nullptr, nA, 1, nqM, d_perm, a_M, p->aMp);
+                hipLaunchKernelGGL(repack_kernel, dim3(stream_grid(nA, 256)), dim3(256), 0, nullptr, nA, 1, nqM, pe, d_perm, a_M, p->aMp);
             ok(launch_status());
             ok(static_cast<int>(hipDeviceSynchronize()));
         }
@@ -1848,8 +1861,24 @@ extern "C"
         *out = nullptr;
         if (!supported(nb, nqS, nqM) || n_elem <= 0)
             return static_cast<int>(hipErrorNotSupported);
+        int pe = helm_mfma(nb, nqS, nqM) ? 16 : PE;
+        if (pe == PE && nb <= 4)
+        {
+            // Affine plans (uniform stiffness metric, read through scalar loads) use 64-element patches, two wavefronts sharing
+            // one LDS copy: a third fewer border dofs and slots.  Measured at 1024^2: n_basis 4 331 -> 316 us, n_basis 3
+            // 137 -> 130 us; with per-element metrics the larger patch is a wash on structured meshes and 6 % slower on
+            // the irregular one (the two waves wait for each other at every colour phase), n_basis 5 does not change.
+            const char *a = std::getenv("CUDDH_PLAN_AFFINE");
+            double *probe = nullptr;
+            if (!(a && std::atoi(a) == 0) && uniform_table(&probe, 3, nqS, n_elem, G_S) == 0 && probe)
+                pe = 64;
+            if (probe)
+                (void)hipFree(probe);
+            if (const char *e = std::getenv("CUDDH_HELM_PE")) // measurement knob
+                pe = std::atoi(e) == 64 ? 64 : PE;
+        }
         return build_plan(out, ndof, n_elem, nb, h_I, h_xy, nqS, h_PS, h_DS, G_S, nqM, h_PM, a_M, n_faces, h_fI, h_face_elem, nqF,
-                          h_PF, a_F, helm_mfma(nb, nqS, nqM) ? 16 : PE);
+                          h_PF, a_F, pe);
     }
 
     int cuddh_hip_operator_plan_create(cuddh_helmholtz_plan **out, int kind, int ndof, int n_elem, int nb, const int *h_I,

@@ -4,6 +4,9 @@
 #include "cuddh/ddh.hpp"
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cmath>
 #include <type_traits>
 #include <vector>
@@ -29,6 +32,21 @@ namespace cuddh
             }
         } // namespace
 
+        // CUDDH_SETUP_TIMING=1 prints the wall time of each constructor phase (host work, once per solver)
+        struct PhaseTimer
+        {
+            const bool on = std::getenv("CUDDH_SETUP_TIMING") != nullptr;
+            std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+            void lap(const char *what)
+            {
+                if (!on)
+                    return;
+                const auto t1 = std::chrono::steady_clock::now();
+                std::fprintf(stderr, "[cuddh setup] %-28s %8.3f s\n", what, std::chrono::duration<double>(t1 - t0).count());
+                t0 = t1;
+            }
+        };
+
         template <typename Real>
         DDHCore<Real>::DDHCore(double omega_, const double *h_a, const H1Space &fem, int nx, int ny, int kernel)
             : g_ndof(fem.size()), g_elem(fem.mesh().n_elem()), n_basis(fem.basis().size()), omega(omega_), fem_mesh(&fem.mesh()),
@@ -45,6 +63,7 @@ namespace cuddh
             if (nx * ny != g_elem)
                 cuddh_error("DDH error: nx * ny does not match the mesh.");
 
+            PhaseTimer timer;
             const int ndx = nx / nel1d, ndy = ny / nel1d;
             n_domains = ndx * ndy;
             std::vector<int> labels(static_cast<std::size_t>(nx) * ny);
@@ -53,6 +72,7 @@ namespace cuddh
                     labels[i + static_cast<std::size_t>(nx) * j] = (i / nel1d) + ndx * (j / nel1d);
 
             efem.reset(new EnsembleSpace(fem, n_domains, labels.data()));
+            timer.lap("EnsembleSpace");
 
             // ---- WaveHoltz time grid: dt = 0.1 h / nb^2 shrunk so that nt dt is one period
             const double T = 2.0 * M_PI / omega;
@@ -79,6 +99,7 @@ namespace cuddh
                 sn[k] = static_cast<Real>(std::sin(omega * t));
             }
 
+            timer.lap("time grid tables");
             // ---- extents
             auto sizes = efem->sizes(MemorySpace::HOST);
             auto fsizes = efem->fsizes(MemorySpace::HOST);
@@ -111,6 +132,7 @@ namespace cuddh
                 B(j1, 1, S1) = k;
             }
 
+            timer.lap("trace slots");
             // ---- renumber each subdomain so that its face dofs come first (in face-space order)
             auto faceproj = efem->face_proj(MemorySpace::HOST);
             auto g_inds = efem->global_indices(MemorySpace::HOST);
@@ -147,6 +169,7 @@ namespace cuddh
                             sI(k, l, el, s) = new_of_old[s_inds(k, l, el, s)];
             }
 
+            timer.lap("face-first renumbering");
             // ---- local operators
             const Basis &basis = fem.basis();
             const QuadratureRule &q = basis.quadrature();
@@ -164,6 +187,7 @@ namespace cuddh
             auto detJ = reshape(metrics.measures(MemorySpace::HOST), nb, nb, g_elem);
             auto fem_gi = fem.global_indices(MemorySpace::HOST);
 
+            timer.lap("element metrics");
             // global lumped mass and its inverse
             std::vector<double> inv_mass(g_ndof, 0.0);
             for (int el = 0; el < g_elem; ++el)
@@ -215,6 +239,7 @@ namespace cuddh
                 }
             }
 
+            timer.lap("lumped masses, H, a");
             requested_kernel = kernel;
         }
 
