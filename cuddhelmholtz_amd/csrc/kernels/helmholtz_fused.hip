@@ -5,7 +5,7 @@
 // Kernels in this file
 //   helm_patch_kernel   n_basis 2-5, complex: one element per lane, lanes 0-31 u / 32-63 v; patches of 32 elements (one
 //                       wavefront) or, for affine plans, 64 (two wavefronts sharing the LDS copy)
-//   op_patch_kernel     n_basis 2-5, real   : one element per lane, two patches of 32 per wavefront
+//   op_patch_kernel     n_basis 2-5, real   : one element per lane, one patch of 64 elements per wavefront
 //   helm_mfma_kernel    n_basis 6-8, complex: batches of 16 elements, 1-D contractions on v_mfma_f64_16x16x4_f64
 //   op_mfma_kernel      n_basis 6-8, real   : the same for one operator
 //   helm_border_kernel / op_border_kernel: sums of the per-patch contributions at dofs shared by several patches
@@ -639,49 +639,52 @@ namespace
     }
 
     // ---------------------------------------------------------------- one real operator through the same plan
-    // y = [y +] c * S x  (KIND 0)  or  y = [y +] c * M x  (KIND 1) on a real vector.  Same patches, layouts and colour
-    // phases as the complex kernel; the two half-waves now work on two DIFFERENT patches (2*pair and 2*pair + 1), so
-    // every metric load instruction still fetches 2 x 256 contiguous bytes and no lane idles.
+    // y = [y +] c * S x  (KIND 0)  or  y = [y +] c * M x  (KIND 1) on a real vector.  Same layouts and colour phases as the
+    // complex kernel; a wavefront owns one 64-element patch (PEK = 64, the default) or two 32-element patches, one per
+    // half-wave (PEK = 32, kept for comparison): every metric load instruction fetches 512 contiguous bytes, no lane idles.
     // UM: the metric array of this operator is the same in every element and comes from the uniform table MU
-    template <int NB, int NQ, int KIND, bool NT, bool UM>
+    // PEK = 32: two patches of 32 elements per wavefront; PEK = 64: one patch of 64 (a third fewer border dofs and slots)
+    template <int NB, int NQ, int KIND, bool NT, bool UM, int PEK>
     __global__ void __launch_bounds__(64, (NB >= 5 ? 2 : ((NB == 4 && KIND == 0 && !UM) ? 3 : 4))) op_patch_kernel(HelmArgs A, int accumulate, const double *__restrict__ P,
                                                                              const double *__restrict__ D, const double *__restrict__ MU)
     {
         constexpr int NN = NB * NB, NP = (NN + 1) / 2;
         constexpr int NM = (KIND == 0 ? 3 : 1) * NQ; // metric values of one slice
         extern __shared__ double lds[];
+        constexpr bool ONE = PEK == 64;
         const int pair = (blockIdx.x & 7) * A.xcd_chunk + (blockIdx.x >> 3);
-        if (2 * pair >= A.n_patches)
+        const int first = ONE ? pair : 2 * pair; // first (or only) patch of this wavefront
+        if (first >= A.n_patches)
             return; // whole workgroup
         const int lane = threadIdx.x;
-        const int half = lane >> 5, le = lane & 31;
+        const int half = ONE ? 0 : lane >> 5, le = ONE ? lane : lane & 31;
         const int ML = A.max_loc;
-        double *xs = lds;          // [2 patches][ML]
-        double *ys = lds + 2 * ML; // [2 patches][ML]
-        const int n_here = min(2, A.n_patches - 2 * pair);
+        double *xs = lds;                      // [patches of this wavefront][ML]
+        double *ys = lds + (ONE ? 1 : 2) * ML; // the same
+        const int n_here = ONE ? 1 : min(2, A.n_patches - first);
 
         // the dof lists of the two patches are adjacent: one combined list, split at n0
-        const int off = A.dof_off[2 * pair];
-        const int n0 = A.dof_off[2 * pair + 1] - off;
-        const int ntot = A.dof_off[2 * pair + n_here] - off;
+        const int off = A.dof_off[first];
+        const int n0 = A.dof_off[first + 1] - off;
+        const int ntot = A.dof_off[first + n_here] - off;
         const int *dofs = A.dof_list + off;
 
         // requests that do not depend on the LDS copy of x go out first (see helm_patch_kernel)
         const bool have = half < n_here;
-        const int patch = have ? 2 * pair + half : 2 * pair; // a missing second patch re-reads the first (results dropped)
+        const int patch = have ? first + half : first; // a missing second patch re-reads the first (results dropped)
         const bool active = have && le < A.patch_nel[patch];
-        const uint32_t *li = A.lidx + ((size_t)patch * NP) * PE + le;
+        const uint32_t *li = A.lidx + ((size_t)patch * NP) * PEK + le;
         uint32_t lpk[NP];
 #pragma unroll
         for (int j = 0; j < NP; ++j)
-            lpk[j] = li[j * PE];
-        const int mycol = active ? A.colour[patch * PE + le] : -1;
-        const double *Mp = (KIND == 0 ? A.Gp + (size_t)patch * 3 * NQ * NQ * PE : A.aMp + (size_t)patch * NQ * NQ * PE) + le;
+            lpk[j] = li[j * PEK];
+        const int mycol = active ? A.colour[patch * PEK + le] : -1;
+        const double *Mp = (KIND == 0 ? A.Gp + (size_t)patch * 3 * NQ * NQ * PEK : A.aMp + (size_t)patch * NQ * NQ * PEK) + le;
         auto load_slice = [&](int q, double (&g)[NM])
         {
 #pragma unroll
             for (int t = 0; t < NM; ++t) // KIND 0: t = c * NQ + r (component c of point (q, r)); KIND 1: t = r
-                g[t] = UM ? MU[q * NM + t] : metric_load<NT>(&Mp[(q * NM + t) * PE]);
+                g[t] = UM ? MU[q * NM + t] : metric_load<NT>(&Mp[(q * NM + t) * PEK]);
         };
         double g_first[NM];
         if constexpr (!UM)
@@ -1499,18 +1502,27 @@ namespace
         return kind == 1 && (nq == nb + 1 || nq == 2 + 3 * nb / 2);
     }
 
-    template <int NB, int NQ, int KIND>
-    void launch_op_one(const cuddh_helmholtz_plan *p, const HelmArgs &A, int accumulate, hipStream_t st)
+    template <int NB, int NQ, int KIND, int PEK>
+    void launch_op_pe(const cuddh_helmholtz_plan *p, const HelmArgs &A, int accumulate, hipStream_t st)
     {
-        const size_t lds = (size_t)4 * p->max_loc * sizeof(double);
+        const size_t lds = (size_t)(PEK == 64 ? 2 : 4) * p->max_loc * sizeof(double);
         const dim3 grid(8 * A.xcd_chunk), block(64);
         const double *P = KIND == 0 ? p->PS : p->PM, *MU = KIND == 0 ? p->Gu : p->au;
         if (MU)
-            hipLaunchKernelGGL((op_patch_kernel<NB, NQ, KIND, false, true>), grid, block, lds, st, A, accumulate, P, p->DS, MU);
+            hipLaunchKernelGGL((op_patch_kernel<NB, NQ, KIND, false, true, PEK>), grid, block, lds, st, A, accumulate, P, p->DS, MU);
         else if (p->streaming)
-            hipLaunchKernelGGL((op_patch_kernel<NB, NQ, KIND, true, false>), grid, block, lds, st, A, accumulate, P, p->DS, MU);
+            hipLaunchKernelGGL((op_patch_kernel<NB, NQ, KIND, true, false, PEK>), grid, block, lds, st, A, accumulate, P, p->DS, MU);
         else
-            hipLaunchKernelGGL((op_patch_kernel<NB, NQ, KIND, false, false>), grid, block, lds, st, A, accumulate, P, p->DS, MU);
+            hipLaunchKernelGGL((op_patch_kernel<NB, NQ, KIND, false, false, PEK>), grid, block, lds, st, A, accumulate, P, p->DS, MU);
+    }
+
+    template <int NB, int NQ, int KIND>
+    void launch_op_one(const cuddh_helmholtz_plan *p, const HelmArgs &A, int accumulate, hipStream_t st)
+    {
+        if (p->pe == 64)
+            launch_op_pe<NB, NQ, KIND, 64>(p, A, accumulate, st);
+        else
+            launch_op_pe<NB, NQ, KIND, 32>(p, A, accumulate, st);
     }
 
     bool launch_op(const cuddh_helmholtz_plan *p, const HelmArgs &A, int accumulate, hipStream_t st)
@@ -1887,7 +1899,12 @@ extern "C"
         *out = nullptr;
         if (n_elem <= 0 || !op_supported(kind, nb, nq))
             return static_cast<int>(hipErrorNotSupported);
-        const int pe = op_mfma(kind, nb, nq) ? 16 : PE;
+        // n_basis 2-5: one 64-element patch per wavefront (8x8 elements on a structured mesh).  Two 32-element patches per
+        // wavefront (CUDDH_OP_PE=32) have a third more border dofs and slots: 1024^2, n_basis 4, general layout: stiffness
+        // 174-187 -> 162-171 us, mass 109 -> 97 us, weighted mass 168 -> 153 us; affine 113 / 87 / 98 -> 98 / 75 / 82 us.
+        int pe = op_mfma(kind, nb, nq) ? 16 : 64;
+        if (const char *e = std::getenv("CUDDH_OP_PE")) // measurement knob
+            pe = (pe != 16 && std::atoi(e) == 32) ? PE : pe;
         if (kind == 0)
             return build_plan(out, ndof, n_elem, nb, h_I, h_xy, nq, h_P, h_D, metric, 0, nullptr, nullptr, 0, nullptr, nullptr, 0,
                               nullptr, nullptr, pe);
@@ -1931,8 +1948,8 @@ extern "C"
         }
         else
         {
-            const int n_pairs = (p->n_patches + 1) / 2;
-            A.xcd_chunk = (n_pairs + 7) / 8;
+            const int n_waves = p->pe == 64 ? p->n_patches : (p->n_patches + 1) / 2; // two 32-element patches per wavefront
+            A.xcd_chunk = (n_waves + 7) / 8;
             if (!launch_op(p, A, accumulate, st))
                 return static_cast<int>(hipErrorNotSupported);
         }
