@@ -119,8 +119,14 @@ namespace
         // every wavefront holds 32 elements, u in lanes 0-31 and v in lanes 32-63, so that a metric value is loaded once
         const int comp = (lane >> 5) & 1, le = (lane & 31) + 32 * (lane >> 6);
         const int ML = A.max_loc;
+        // PEK = 32: xs = [2][ML] copy of x, ys = [2][ML] accumulator.  PEK = 64: every wavefront accumulates its 32 elements
+        // in its OWN [2][ML] array, so that the two waves meet at three barriers only (after the gather, after the register
+        // fill, before the write-out) instead of at every colour phase: wave 1 uses ys, wave 0 re-uses xs once both waves
+        // have filled their registers from it; the write-out adds the two.
+        constexpr bool TWO = PEK == 64;
         double *xs = lds;          // [2][ML]
         double *ys = lds + 2 * ML; // [2][ML]
+        double *yw = (TWO && (lane >> 6) == 0) ? xs : ys; // this wavefront's accumulator
 
         const int off = A.dof_off[patch];
         const int nloc = A.dof_off[patch + 1] - off;
@@ -207,6 +213,17 @@ namespace
         {
             u[n] = keep * xc[lix_of(n)];
             out[n] = 0.0;
+        }
+
+        if constexpr (TWO)
+        {
+            __syncthreads(); // both waves hold their u: xs becomes wave 0's accumulator
+            if ((lane >> 6) == 0)
+                for (int i = lane; i < nloc; i += 64)
+                {
+                    xs[i] = 0.0;
+                    xs[ML + i] = 0.0;
+                }
         }
 
         // One quadrature "slice" = all points with the same xi index q.
@@ -345,7 +362,7 @@ namespace
         // accumulate: elements of one colour touch disjoint dofs
         {
             const double sgn = comp ? -1.0 : 1.0; // the v row is negated (symmetrised system)
-            double *yc = ys + comp * ML;
+            double *yc = yw + comp * ML;
             for (int c = 0; c < A.ncol; ++c)
             {
                 if (mycol == c)
@@ -354,15 +371,19 @@ namespace
                     for (int n = 0; n < NN; ++n)
                         yc[lix_of(n)] += sgn * out[n];
                 }
-                __syncthreads();
+                if constexpr (TWO)
+                    __builtin_amdgcn_wave_barrier(); // the accumulator is private to the wave: LDS operations of one wave are in order
+                else
+                    __syncthreads();
             }
         }
 
         // ------------------------------------------------------------ boundary faces:  Au -= w H v,  Av -= w H u
         {
             const int f_begin = A.face_off[patch], nf = A.face_off[patch + 1] - f_begin;
-            const double *xo = xs + (1 - comp) * ML; // the other component
-            double *yc = ys + comp * ML;
+            const double *xo = xs + (1 - comp) * ML; // the other component (PEK = 32)
+            const double *xg = A.x + (size_t)(1 - comp) * A.ndof; // PEK = 64: xs is gone, the few face values come from global memory
+            double *yc = yw + comp * ML;
             const int nqF = A.nqF;
             for (int f0 = 0; f0 < nf; f0 += PEK)
             {
@@ -387,7 +408,7 @@ namespace
                     for (int k = 0; k < NB; ++k)
                     {
                         fl[k] = fli[k];
-                        w[k] = xo[fl[k]];
+                        w[k] = TWO ? xg[dofs[fl[k]]] : xo[fl[k]];
                     }
                     for (int q = 0; q < nqF; ++q)
                     {
@@ -409,12 +430,18 @@ namespace
                         for (int k = 0; k < NB; ++k)
                             yc[fl[k]] -= A.omega * res[k];
                     }
-                    __syncthreads();
+                    if constexpr (TWO)
+                        __builtin_amdgcn_wave_barrier();
+                    else
+                        __syncthreads();
                 }
             }
         }
 
         // ------------------------------------------------------------ write out
+        if constexpr (TWO)
+            __syncthreads(); // both accumulators complete
+        auto result = [&](int i) -> double { return TWO ? xs[i] + ys[i] : ys[i]; };
         for (int base = 0; base < nloc; base += NTH * ROWS)
         {
             int dest[ROWS]; // one index per dof: global dof (owned) or -(slot) - 1 (border)
@@ -429,14 +456,14 @@ namespace
                     continue;
                 if (dest[j] >= 0)
                 {
-                    A.y[dest[j]] = ys[i];
-                    A.y[A.ndof + dest[j]] = ys[ML + i];
+                    A.y[dest[j]] = result(i);
+                    A.y[A.ndof + dest[j]] = result(ML + i);
                 }
                 else
                 {
                     const int sl = -dest[j] - 1;
-                    A.part[sl] = ys[i];
-                    A.part[A.n_slots + sl] = ys[ML + i];
+                    A.part[sl] = result(i);
+                    A.part[A.n_slots + sl] = result(ML + i);
                 }
             }
         }
