@@ -395,6 +395,26 @@ def helmholtz_roofline(cd, torch, dev, fem, mesh, omega, ndof):
     os.environ["CUDDH_PLAN_AFFINE"] = "0"
     A = cd.HelmholtzOperator(omega, a2, ax, fem, fs)
     t = timed(A)
+    # the two real operators the fused apply is made of, alone, same general layout (n_elem (metric + nb^2 4) + ndof 16)
+    nb_, ne_ = fem.basis.n, mesh.n_elem()
+    xr, yr = x[:ndof], y[:ndof]
+    singles = {}
+    for name, op, comps, nq in (("StiffnessMatrix::action", cd.StiffnessMatrix(fem), 3, nb_ + 1),
+                                ("MassMatrix::action (weighted)", cd.MassMatrix(fem, a2), 1, 1 + 3 * nb_ // 2 + 1)):
+        for _ in range(5):
+            op.action(xr, yr)
+        torch.cuda.synchronize()
+        s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s0.record()
+        for _ in range(30):
+            op.action(xr, yr)
+        s1.record()
+        torch.cuda.synchronize()
+        ts = s0.elapsed_time(s1) * 1e-3 / 30
+        bs = ne_ * (comps * nq * nq * 8 + nb_ * nb_ * 4) + ndof * 16
+        singles[name] = {"seconds_per_apply": ts, "algorithmic_bytes": bs, "achieved": bs / ts / 1e9, "unit": "GB/s",
+                         "frac": bs / ts / 1e9 / HBM_PEAK_GBS}
+        del op
     os.environ["CUDDH_PLAN_AFFINE"] = "1"
     A_aff = cd.HelmholtzOperator(omega, a2, ax, fem, fs)
     affine = None
@@ -434,6 +454,7 @@ def helmholtz_roofline(cd, torch, dev, fem, mesh, omega, ndof):
         "seconds_per_apply": t,
         "complex_dof_per_s": ndof / t,
         "affine": affine,
+        "single_operators": singles,  # real vectors, general layout, y = Op x through the same plan machinery
     }
 
 
