@@ -179,7 +179,6 @@ namespace cuddh
             const int m = quad.size(), nel = mesh.n_elem();
             out.resize(dim * m * m * nel);
             double *dst = out.host_write();
-#pragma omp parallel for schedule(static)
             for (int el = 0; el < nel; ++el)
             {
                 const Element *e = mesh.element(el);
