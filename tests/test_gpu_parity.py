@@ -324,6 +324,60 @@ def test_affine_and_general_plans_agree(cuda, nb, monkeypatch):
         assert rel(a, b) < 1e-13
 
 
+# ------------------------------------------------------------------ patch sizes
+@pytest.mark.parametrize("kind,nx", [("structured", 13), ("unstructured", 0)])
+@pytest.mark.parametrize("nb", [2, 4, 5])
+def test_patch_sizes_agree(cuda, kind, nx, nb, monkeypatch):
+    """The plan kernels exist for 32- and 64-element patches (real operators: 64 by default; fused apply: 64 for affine
+    plans, 32 otherwise).  CUDDH_OP_PE / CUDDH_HELM_PE force either size; every combination must match the oracle and
+    the results of the two sizes must agree to rounding (the summation order inside a patch differs)."""
+    import torch
+
+    import cuddhelmholtz_amd as cd
+
+    pm, om = meshes(kind, nx)
+    d = oracle.Discretization(om, nb)
+    rng = np.random.default_rng(70 + nb)
+    xh = rng.standard_normal(2 * d.ndof)
+    a2 = 0.5 + rng.random(d.ndof)
+    faces = pm.boundary_edges()
+    ofs = oracle.FaceSpaceO(d, list(faces))
+    ax = 0.5 + rng.random(ofs.size)
+    omega = 5.0
+    refS = oracle.Stiffness(d).apply(xh[: d.ndof])
+    refM = oracle.Mass(d, a2).apply(xh[: d.ndof])
+    refA = oracle.helmholtz_apply(d, oracle.Stiffness(d), oracle.Mass(d, a2), oracle.FaceMass(ofs, ax), ofs, omega, xh)
+    got = {}
+    for pe in ("32", "64"):
+        for affine in ("1", "0"):
+            monkeypatch.setenv("CUDDH_OP_PE", pe)
+            monkeypatch.setenv("CUDDH_HELM_PE", pe)
+            monkeypatch.setenv("CUDDH_PLAN_AFFINE", affine)
+            fem = cd.H1Space(pm, cd.Basis(nb))
+            fs = cd.FaceSpace(fem, faces)
+            x = to_dev(torch, xh, cuda)
+            a2d = to_dev(torch, a2, cuda)
+            yS = torch.full((d.ndof,), -2.0, dtype=torch.float64, device=cuda)
+            yM = torch.full((d.ndof,), -2.0, dtype=torch.float64, device=cuda)
+            cd.StiffnessMatrix(fem).action(x[: d.ndof], yS)
+            cd.MassMatrix(fem, a2d).action(x[: d.ndof], yM)
+            A = cd.HelmholtzOperator(omega, a2d, to_dev(torch, ax, cuda), fem, fs)
+            y = torch.empty(2 * d.ndof, dtype=torch.float64, device=cuda)
+            A.action(x, y)
+            assert A.fused()
+            assert rel(yS.cpu().numpy(), refS) < 1e-12 and rel(yM.cpu().numpy(), refM) < 1e-12
+            assert rel(y.cpu().numpy(), refA) < 1e-12
+            # accumulate form: y <- y + c Op x
+            yS2 = to_dev(torch, refS, cuda).clone()
+            cd.StiffnessMatrix(fem).action(-1.0, x[: d.ndof], yS2)
+            assert float(yS2.abs().max()) < 1e-11 * float(np.abs(refS).max())
+            got[(pe, affine)] = (yS.cpu().numpy(), yM.cpu().numpy(), y.cpu().numpy())
+    base = got[("32", "0")]
+    for key, val in got.items():
+        for a, b in zip(val, base):
+            assert rel(a, b) < 1e-13, key
+
+
 # ------------------------------------------------------------------ fused Helmholtz apply
 @pytest.mark.parametrize("kind,nx", [("structured", 10), ("structured", 37), ("unstructured", 0)])
 @pytest.mark.parametrize("nb", [2, 3, 4, 5, 6, 7, 8])
