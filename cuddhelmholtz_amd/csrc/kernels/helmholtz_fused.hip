@@ -103,7 +103,7 @@ namespace
     // UG: the stiffness metric is the same in every element and comes from the uniform table GU (scalar loads)
     // PEK elements per patch: 32 = one wavefront, 64 = two wavefronts sharing the LDS copy of a larger patch (fewer border dofs)
     template <int NB, int NQS, int NQM, bool NT, bool UG, int PEK>
-    __global__ void __launch_bounds__(2 * PEK, (NB >= 5 ? 2 : ((NB == 4 && !UG) ? 3 : 4))) helm_patch_kernel(HelmArgs A, const double *__restrict__ PS, const double *__restrict__ DS,
+    __global__ void __launch_bounds__(2 * PEK, (NB >= 5 ? (UG ? 2 : 3) : ((NB == 4 && !UG) ? 3 : 4))) helm_patch_kernel(HelmArgs A, const double *__restrict__ PS, const double *__restrict__ DS,
                                                            const double *__restrict__ PM, const double *__restrict__ PF,
                                                            const double *__restrict__ GU)
     {
@@ -148,6 +148,8 @@ namespace
         for (int j = 0; j < NP; ++j)
             lpk[j] = li[j * PEK];
         const int mycol = active ? A.colour[patch * PEK + le] : -1;
+        // n_basis 5, general layout: 3 waves/SIMD with 26 spilled registers measured 1-14 % faster than 2 waves without
+        // (same-box A/B, 256^2 ... 1024^2 and the irregular mesh); the affine form loses 30 % that way and stays at 2.
         // n_basis 4, general layout: 153 VGPRs at 3 waves/SIMD (no spills, first slice prefetched) measured faster than
         // 128 VGPRs with 8 spilled at 4 waves/SIMD (1024^2: 402 vs 420 us; irregular 0.49 M quads: 187 vs 222 us)
         constexpr bool PRE = !UG && NB <= 4;
