@@ -5,6 +5,8 @@
 // Kernels in this file
 //   helm_patch_kernel   n_basis 2-5, complex: one element per lane, lanes 0-31 u / 32-63 v; patches of 32 elements (one
 //                       wavefront) or, for affine plans, 64 (two wavefronts sharing the LDS copy)
+//   helm_lane_kernel    n_basis 4, complex, general geometry, >= 512^2 elements: lane = element, both components per lane,
+//                       64-element patches, one wavefront each
 //   op_patch_kernel     n_basis 2-5, real   : one element per lane, one patch of 64 elements per wavefront
 //   helm_mfma_kernel    n_basis 6-8, complex: batches of 16 elements, 1-D contractions on v_mfma_f64_16x16x4_f64
 //   op_mfma_kernel      n_basis 6-8, real   : the same for one operator
@@ -66,6 +68,7 @@ struct cuddh_helmholtz_plan
     double *part = nullptr; // [2][n_slots]
     size_t bytes_alg = 0, bytes_actual = 0;
     int streaming = 0; // metric loads carry the non-temporal hint (plans larger than the infinity cache)
+    int lane_form = 0; // fused apply through helm_lane_kernel (one element per lane, both components)
     size_t bytes_affine = 0; // algorithmic bytes of the affine form (0 when neither metric array is uniform)
 };
 
@@ -471,6 +474,335 @@ namespace
         }
     }
 
+    // ---------------------------------------------------------------- fused complex apply, one element per lane, BOTH components
+    // Patches of 64 elements, one wavefront per patch, lane = element: the lane applies the operators to u and then to v of
+    // its element with the same metric values.  Against helm_patch_kernel (32 elements x 2 components per wavefront) every
+    // metric load instruction fetches 512 distinct bytes instead of 256, so a wavefront keeps twice the bytes in flight per
+    // round trip of its chain; the price is twice the element state per lane (2 waves per SIMD instead of 3).  The LDS copy of
+    // x is consumed when the registers are filled and the same array then accumulates y (as in helm_mfma_kernel); the
+    // boundary-face term re-reads its few x values from global memory.
+    template <int NB, int NQS, int NQM, bool NT>
+    __global__ void __launch_bounds__(64, 2) helm_lane_kernel(HelmArgs A, const double *__restrict__ PS, const double *__restrict__ DS,
+                                                              const double *__restrict__ PM, const double *__restrict__ PF)
+    {
+        constexpr int NN = NB * NB, NP = (NN + 1) / 2, PEK = 64;
+        extern __shared__ double lds[];
+        const int patch = (blockIdx.x & 7) * A.xcd_chunk + (blockIdx.x >> 3);
+        if (patch >= A.n_patches)
+            return; // whole workgroup
+        const int lane = threadIdx.x;
+        const int ML = A.max_loc;
+        double *xy = lds; // [2][ML]: the gathered x, then the accumulated y
+
+        const int off = A.dof_off[patch];
+        const int nloc = A.dof_off[patch + 1] - off;
+        const int *dofs = A.dof_list + off;
+        const double *Gp = A.Gp + (size_t)patch * 3 * NQS * NQS * PEK + lane;
+        const double *ap = A.aMp + (size_t)patch * NQM * NQM * PEK + lane;
+
+        const bool active = lane < A.patch_nel[patch];
+        const uint32_t *li = A.lidx + ((size_t)patch * NP) * PEK + lane;
+        uint32_t lpk[NP];
+#pragma unroll
+        for (int j = 0; j < NP; ++j)
+            lpk[j] = li[j * PEK];
+        const int mycol = active ? A.colour[patch * PEK + lane] : -1;
+        double g_first[3 * NQS]; // first stiffness slice, requested before the gather
+#pragma unroll
+        for (int r = 0; r < NQS; ++r)
+        {
+            g_first[3 * r + 0] = metric_load<NT>(&Gp[((0 * 3 + 0) * NQS + r) * PEK]);
+            g_first[3 * r + 1] = metric_load<NT>(&Gp[((0 * 3 + 1) * NQS + r) * PEK]);
+            g_first[3 * r + 2] = metric_load<NT>(&Gp[((0 * 3 + 2) * NQS + r) * PEK]);
+        }
+
+        constexpr int ROWS = 10; // 640 dofs per pass: an 8x8-element patch of n_basis 4 (625) in one
+        for (int base = 0; base < nloc; base += 64 * ROWS)
+        {
+            int gi[ROWS];
+#pragma unroll
+            for (int j = 0; j < ROWS; ++j)
+                gi[j] = dofs[min(base + 64 * j + lane, nloc - 1)];
+            double xu[ROWS], xv[ROWS];
+#pragma unroll
+            for (int j = 0; j < ROWS; ++j)
+            {
+                xu[j] = A.x[gi[j]];
+                xv[j] = A.x[A.ndof + gi[j]];
+            }
+#pragma unroll
+            for (int j = 0; j < ROWS; ++j)
+            {
+                const int i = base + 64 * j + lane;
+                if (i < nloc)
+                {
+                    xy[i] = xu[j];
+                    xy[ML + i] = xv[j];
+                }
+            }
+        }
+        __syncthreads();
+
+        auto lix_of = [&](int n) -> int { return (n & 1) ? static_cast<int>(lpk[n >> 1] >> 16) : static_cast<int>(lpk[n >> 1] & 0xFFFFu); };
+        const double keep = active ? 1.0 : 0.0;
+        double u[2][NN], out[2][NN];
+#pragma unroll
+        for (int n = 0; n < NN; ++n)
+        {
+            const int l = lix_of(n);
+            u[0][n] = keep * xy[l];
+            u[1][n] = keep * xy[ML + l];
+            out[0][n] = 0.0;
+            out[1][n] = 0.0;
+        }
+        __syncthreads();
+        for (int i = lane; i < nloc; i += 64)
+        {
+            xy[i] = 0.0;
+            xy[ML + i] = 0.0;
+        }
+        __syncthreads();
+
+        auto stiff_slice = [&](int q, const double (&g)[3 * NQS])
+        {
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+            {
+                double pu[NB], du[NB], t0[NB], t1[NB];
+#pragma unroll
+                for (int l = 0; l < NB; ++l)
+                {
+                    double a = 0.0, b = 0.0;
+#pragma unroll
+                    for (int k = 0; k < NB; ++k)
+                    {
+                        a += PS[q + NQS * k] * u[c][k + NB * l];
+                        b += DS[q + NQS * k] * u[c][k + NB * l];
+                    }
+                    pu[l] = a;
+                    du[l] = b;
+                    t0[l] = 0.0;
+                    t1[l] = 0.0;
+                }
+#pragma unroll
+                for (int r = 0; r < NQS; ++r)
+                {
+                    const double ga = g[3 * r + 0], gb = g[3 * r + 1], gc = g[3 * r + 2];
+                    double dx = 0.0, dy = 0.0;
+#pragma unroll
+                    for (int l = 0; l < NB; ++l)
+                    {
+                        dx += PS[r + NQS * l] * du[l];
+                        dy += DS[r + NQS * l] * pu[l];
+                    }
+                    const double f0 = ga * dx + gb * dy;
+                    const double f1 = gb * dx + gc * dy;
+#pragma unroll
+                    for (int l = 0; l < NB; ++l)
+                    {
+                        t0[l] += PS[r + NQS * l] * f0;
+                        t1[l] += DS[r + NQS * l] * f1;
+                    }
+                }
+#pragma unroll
+                for (int l = 0; l < NB; ++l)
+#pragma unroll
+                    for (int k = 0; k < NB; ++k)
+                        out[c][k + NB * l] += DS[q + NQS * k] * t0[l] + PS[q + NQS * k] * t1[l];
+            }
+        };
+        const double w2 = -A.omega * A.omega;
+        auto mass_slice = [&](int q, const double (&am)[NQM])
+        {
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+            {
+                double pu[NB], t[NB];
+#pragma unroll
+                for (int l = 0; l < NB; ++l)
+                {
+                    double a = 0.0;
+#pragma unroll
+                    for (int k = 0; k < NB; ++k)
+                        a += PM[q + NQM * k] * u[c][k + NB * l];
+                    pu[l] = a;
+                    t[l] = 0.0;
+                }
+#pragma unroll
+                for (int r = 0; r < NQM; ++r)
+                {
+                    double val = 0.0;
+#pragma unroll
+                    for (int l = 0; l < NB; ++l)
+                        val += PM[r + NQM * l] * pu[l];
+                    val *= am[r] * w2;
+#pragma unroll
+                    for (int l = 0; l < NB; ++l)
+                        t[l] += PM[r + NQM * l] * val;
+                }
+#pragma unroll
+                for (int l = 0; l < NB; ++l)
+#pragma unroll
+                    for (int k = 0; k < NB; ++k)
+                        out[c][k + NB * l] += PM[q + NQM * k] * t[l];
+            }
+        };
+
+        stiff_slice(0, g_first);
+#pragma unroll 1
+        for (int q = 1; q < NQS; ++q)
+        {
+            double g[3 * NQS];
+#pragma unroll
+            for (int r = 0; r < NQS; ++r)
+            {
+                g[3 * r + 0] = metric_load<NT>(&Gp[((q * 3 + 0) * NQS + r) * PEK]);
+                g[3 * r + 1] = metric_load<NT>(&Gp[((q * 3 + 1) * NQS + r) * PEK]);
+                g[3 * r + 2] = metric_load<NT>(&Gp[((q * 3 + 2) * NQS + r) * PEK]);
+            }
+            stiff_slice(q, g);
+        }
+        // two mass slices per round trip: 2 x NQM values are no more registers than the 3 x NQS of a stiffness slice, which
+        // are dead by now, and the chain of dependent round trips shrinks from NQS + NQM to NQS + NQM / 2
+#pragma unroll 1
+        for (int q = 0; q + 1 < NQM; q += 2)
+        {
+            double am0[NQM], am1[NQM];
+#pragma unroll
+            for (int r = 0; r < NQM; ++r)
+            {
+                am0[r] = metric_load<NT>(&ap[(q * NQM + r) * PEK]);
+                am1[r] = metric_load<NT>(&ap[((q + 1) * NQM + r) * PEK]);
+            }
+            mass_slice(q, am0);
+            mass_slice(q + 1, am1);
+        }
+        if constexpr (NQM % 2 == 1)
+        {
+            double am[NQM];
+#pragma unroll
+            for (int r = 0; r < NQM; ++r)
+                am[r] = metric_load<NT>(&ap[((NQM - 1) * NQM + r) * PEK]);
+            mass_slice(NQM - 1, am);
+        }
+
+        const int *slot = A.slot_of + off;
+        int dest0[ROWS];
+#pragma unroll
+        for (int j = 0; j < ROWS; ++j)
+            dest0[j] = slot[min(64 * j + lane, nloc - 1)];
+
+        // accumulate in colour phases; the v row is negated (symmetrised system)
+        for (int c = 0; c < A.ncol; ++c)
+        {
+            if (mycol == c)
+            {
+#pragma unroll
+                for (int n = 0; n < NN; ++n)
+                {
+                    const int l = lix_of(n);
+                    xy[l] += out[0][n];
+                    xy[ML + l] -= out[1][n];
+                }
+            }
+            __syncthreads();
+        }
+
+        // boundary faces:  Au -= w H v,  Av -= w H u  (lane = face, both rows)
+        {
+            const int f_begin = A.face_off[patch], nf = A.face_off[patch + 1] - f_begin;
+            const int nqF = A.nqF;
+            for (int f0 = 0; f0 < nf; f0 += 64)
+            {
+                const int f = f0 + lane;
+                const bool fa = f < nf;
+                double ru[NB], rv[NB];
+                int fl[NB];
+                int fc = -1;
+#pragma unroll
+                for (int k = 0; k < NB; ++k)
+                {
+                    ru[k] = 0.0;
+                    rv[k] = 0.0;
+                    fl[k] = 0;
+                }
+                if (fa)
+                {
+                    const uint16_t *fli = A.face_lidx + (size_t)(f_begin + f) * NB;
+                    const double *af = A.aF + (size_t)nqF * A.face_id[f_begin + f];
+                    fc = A.face_col[f_begin + f];
+                    double wu[NB], wv[NB];
+#pragma unroll
+                    for (int k = 0; k < NB; ++k)
+                    {
+                        fl[k] = fli[k];
+                        const int gd = dofs[fl[k]];
+                        wu[k] = A.x[gd];
+                        wv[k] = A.x[A.ndof + gd];
+                    }
+                    for (int q = 0; q < nqF; ++q)
+                    {
+                        double pu = 0.0, pv = 0.0;
+#pragma unroll
+                        for (int k = 0; k < NB; ++k)
+                        {
+                            pu += PF[q + nqF * k] * wu[k];
+                            pv += PF[q + nqF * k] * wv[k];
+                        }
+                        pu *= af[q];
+                        pv *= af[q];
+#pragma unroll
+                        for (int k = 0; k < NB; ++k)
+                        {
+                            ru[k] += PF[q + nqF * k] * pv; // the u row takes H v
+                            rv[k] += PF[q + nqF * k] * pu; // the v row takes H u
+                        }
+                    }
+                }
+                for (int c = 0; c < A.nfcol; ++c)
+                {
+                    if (fc == c)
+                    {
+#pragma unroll
+                        for (int k = 0; k < NB; ++k)
+                        {
+                            xy[fl[k]] -= A.omega * ru[k];
+                            xy[ML + fl[k]] -= A.omega * rv[k];
+                        }
+                    }
+                    __syncthreads();
+                }
+            }
+        }
+
+        // write out
+        for (int base = 0; base < nloc; base += 64 * ROWS)
+        {
+            int dest[ROWS];
+#pragma unroll
+            for (int j = 0; j < ROWS; ++j)
+                dest[j] = base == 0 ? dest0[j] : slot[min(base + 64 * j + lane, nloc - 1)];
+#pragma unroll
+            for (int j = 0; j < ROWS; ++j)
+            {
+                const int i = base + 64 * j + lane;
+                if (i >= nloc)
+                    continue;
+                if (dest[j] >= 0)
+                {
+                    A.y[dest[j]] = xy[i];
+                    A.y[A.ndof + dest[j]] = xy[ML + i];
+                }
+                else
+                {
+                    const int sl = -dest[j] - 1;
+                    A.part[sl] = xy[i];
+                    A.part[A.n_slots + sl] = xy[ML + i];
+                }
+            }
+        }
+    }
+
     __global__ void __launch_bounds__(256) helm_border_kernel(int n_shared, int ndof, int n_slots, const int *__restrict__ shared_dof,
                                                              const int *__restrict__ shared_off,
                                                              const double *__restrict__ part, double *__restrict__ y)
@@ -621,6 +953,17 @@ namespace
     template <int NB, int NQS, int NQM>
     void launch_patch(const cuddh_helmholtz_plan *p, const HelmArgs &A, hipStream_t st)
     {
+        if constexpr (NB == 4)
+            if (p->pe == 64 && !p->Gu && p->lane_form)
+            {
+                const size_t lds = (size_t)2 * p->max_loc * sizeof(double);
+                const dim3 grid(8 * A.xcd_chunk), block(64);
+                if (p->streaming)
+                    hipLaunchKernelGGL((helm_lane_kernel<NB, NQS, NQM, true>), grid, block, lds, st, A, p->PS, p->DS, p->PM, p->PF);
+                else
+                    hipLaunchKernelGGL((helm_lane_kernel<NB, NQS, NQM, false>), grid, block, lds, st, A, p->PS, p->DS, p->PM, p->PF);
+                return;
+            }
         if (p->pe == 64)
             launch_patch_pe<NB, NQS, NQM, 64>(p, A, st);
         else
@@ -1918,8 +2261,19 @@ extern "C"
             if (const char *e = std::getenv("CUDDH_HELM_PE")) // measurement knob
                 pe = std::atoi(e) == 64 ? 64 : PE;
         }
-        return build_plan(out, ndof, n_elem, nb, h_I, h_xy, nqS, h_PS, h_DS, G_S, nqM, h_PM, a_M, n_faces, h_fI, h_face_elem, nqF,
-                          h_PF, a_F, pe);
+        // General geometry, n_basis 4, at least two full rounds of wavefronts (4096 patches of 64 elements = 512^2 elements):
+        // helm_lane_kernel.  Same-box A/B against helm_patch_kernel: 1024^2 403 -> 382 us, 512^2 102.5 -> 91.6 us, irregular
+        // 1.95 M quads 817 -> 764 us; at 256^2 (half a round) it is 10 % slower, hence the size rule.  CUDDH_HELM_LANE=0/1 overrides.
+        bool lane_form = nb == 4 && pe == PE && n_elem >= 4096 * 64;
+        if (const char *e = std::getenv("CUDDH_HELM_LANE"))
+            lane_form = nb == 4 && pe == PE && std::atoi(e) == 1;
+        if (lane_form)
+            pe = 64;
+        const int err = build_plan(out, ndof, n_elem, nb, h_I, h_xy, nqS, h_PS, h_DS, G_S, nqM, h_PM, a_M, n_faces, h_fI, h_face_elem, nqF,
+                                   h_PF, a_F, pe);
+        if (!err && *out)
+            (*out)->lane_form = lane_form && !(*out)->Gu;
+        return err;
     }
 
     int cuddh_hip_operator_plan_create(cuddh_helmholtz_plan **out, int kind, int ndof, int n_elem, int nb, const int *h_I,

@@ -5,7 +5,7 @@ import sys
 from collections import defaultdict
 from pathlib import Path
 
-KEEP = ("helm_patch", "helm_border", "op_patch", "op_border", "ddh_wave", "ddh_block", "ddh_mfma")
+KEEP = ("helm_patch", "helm_lane", "helm_mfma", "helm_border", "op_patch", "op_border", "ddh_wave", "ddh_block", "ddh_mfma")
 
 for root in sys.argv[1:]:
     acc = defaultdict(lambda: defaultdict(list))

@@ -1,5 +1,5 @@
 """Runs one hot kernel a few times (for rocprofv3 counter passes).
-usage: run_kernel.py helm|ddh NX [REPS] [KERNEL]"""
+usage: run_kernel.py helm|stiff|mass|ddh NX [REPS] [KERNEL]"""
 import math
 import os
 import sys
@@ -28,6 +28,12 @@ if which == "helm":
     y = torch.empty_like(x)
     for _ in range(reps):
         A.action(x, y)
+elif which in ("stiff", "mass"):
+    op = cd.StiffnessMatrix(fem) if which == "stiff" else cd.MassMatrix(fem, 0.5 + torch.rand(ndof, dtype=torch.float64, device=dev))
+    x = torch.rand(ndof, dtype=torch.float64, device=dev)
+    y = torch.empty_like(x)
+    for _ in range(reps):
+        op.action(x, y)
 else:
     import numpy as np
 

@@ -92,6 +92,13 @@ def test_fused_helmholtz_linearity_symmetry_determinism_at_full_size(cuda, big, 
     Bx = torch.empty_like(x)
     B.action(x, Bx)
     assert float(torch.linalg.norm(Bx - Ax) / torch.linalg.norm(Ax)) < 1e-13
+    # at this size the general-geometry plan above ran helm_lane_kernel (64-element patches, both components per lane);
+    # the 32-element-patch kernel it replaced there must give the same vector to rounding
+    monkeypatch.setenv("CUDDH_PLAN_AFFINE", "0")
+    monkeypatch.setenv("CUDDH_HELM_LANE", "0")
+    P = cd.HelmholtzOperator(omega, a2, ax, fem, fs)
+    P.action(x, Bx)
+    assert float(torch.linalg.norm(Bx - Ax) / torch.linalg.norm(Ax)) < 1e-13
 
 
 def test_ddh_properties_at_full_size(cuda, big):

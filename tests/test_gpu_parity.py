@@ -329,8 +329,9 @@ def test_affine_and_general_plans_agree(cuda, nb, monkeypatch):
 @pytest.mark.parametrize("nb", [2, 4, 5])
 def test_patch_sizes_agree(cuda, kind, nx, nb, monkeypatch):
     """The plan kernels exist for 32- and 64-element patches (real operators: 64 by default; fused apply: 64 for affine
-    plans, 32 otherwise).  CUDDH_OP_PE / CUDDH_HELM_PE force either size; every combination must match the oracle and
-    the results of the two sizes must agree to rounding (the summation order inside a patch differs)."""
+    plans and, through helm_lane_kernel, for large n_basis-4 plans on general geometry, 32 otherwise).  CUDDH_OP_PE /
+    CUDDH_HELM_PE / CUDDH_HELM_LANE force a form; every combination must match the oracle and the results must agree to
+    rounding (the summation order inside a patch differs)."""
     import torch
 
     import cuddhelmholtz_amd as cd
@@ -348,10 +349,16 @@ def test_patch_sizes_agree(cuda, kind, nx, nb, monkeypatch):
     refM = oracle.Mass(d, a2).apply(xh[: d.ndof])
     refA = oracle.helmholtz_apply(d, oracle.Stiffness(d), oracle.Mass(d, a2), oracle.FaceMass(ofs, ax), ofs, omega, xh)
     got = {}
-    for pe in ("32", "64"):
+    for pe in ("32", "64", "lane"):  # "lane": helm_lane_kernel (n_basis 4, general geometry; chosen by size otherwise)
         for affine in ("1", "0"):
-            monkeypatch.setenv("CUDDH_OP_PE", pe)
-            monkeypatch.setenv("CUDDH_HELM_PE", pe)
+            if pe == "lane":
+                monkeypatch.setenv("CUDDH_OP_PE", "64")
+                monkeypatch.delenv("CUDDH_HELM_PE", raising=False)
+                monkeypatch.setenv("CUDDH_HELM_LANE", "1")
+            else:
+                monkeypatch.setenv("CUDDH_OP_PE", pe)
+                monkeypatch.setenv("CUDDH_HELM_PE", pe)
+                monkeypatch.setenv("CUDDH_HELM_LANE", "0")
             monkeypatch.setenv("CUDDH_PLAN_AFFINE", affine)
             fem = cd.H1Space(pm, cd.Basis(nb))
             fs = cd.FaceSpace(fem, faces)
