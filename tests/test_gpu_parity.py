@@ -326,7 +326,7 @@ def test_affine_and_general_plans_agree(cuda, nb, monkeypatch):
 
 # ------------------------------------------------------------------ patch sizes
 @pytest.mark.parametrize("kind,nx", [("structured", 13), ("unstructured", 0)])
-@pytest.mark.parametrize("nb", [2, 4, 5])
+@pytest.mark.parametrize("nb", [2, 3, 4, 5])
 def test_patch_sizes_agree(cuda, kind, nx, nb, monkeypatch):
     """The plan kernels exist for 32- and 64-element patches (real operators: 64 by default; fused apply: 64 for affine
     plans and, through helm_lane_kernel, for large n_basis-4 plans on general geometry, 32 otherwise).  CUDDH_OP_PE /
