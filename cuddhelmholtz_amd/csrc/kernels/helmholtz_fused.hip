@@ -13,8 +13,8 @@
 //   helm_border_kernel / op_border_kernel: sums of the per-patch contributions at dofs shared by several patches
 //   repack_*, uniform_metric_kernel: plan construction
 //
-// Common design (MI355X): elements are grouped into patches (Morton order of their centroids: 4x8 or 4x4 blocks on a
-// structured mesh); one wavefront owns one patch (or two).
+// Common design (MI355X): elements are grouped into patches (Morton order of their centroids: 8x8, 4x8 or 4x4 blocks on a
+// structured mesh); one wavefront owns one patch, or two wavefronts share one.
 //   * x of the patch's dofs is gathered once into LDS; results are accumulated in LDS in colour phases (elements of one
 //     colour share no dof), i.e. without atomics and in a fixed order;
 //   * the sum factorisation of an element runs in registers; the 1-D interpolation / differentiation matrices are loads
