@@ -441,7 +441,7 @@ def helmholtz_roofline(cd, torch, dev, fem, mesh, omega, ndof):
             break
     return {
         "bound": "hbm",
-        "kernel": (("helm_lane_kernel" if ((nb_ == 4 and ne_ >= 4096 * 64) or (nb_ == 3 and ne_ >= 8192 * 64)) else "helm_patch_kernel" if nb_ <= 5 else "helm_mfma_kernel")
+        "kernel": (("helm_lane_kernel" if ((nb_ == 4 and ne_ >= 4096 * 64) or (nb_ <= 3 and ne_ >= 8192 * 64)) else "helm_patch_kernel" if nb_ <= 5 else "helm_mfma_kernel")
                    + " + helm_border_kernel (fused complex Helmholtz apply)") if A.fused() else "unfused operator sequence",
         "achieved": gbs,
         "peak": HBM_PEAK_GBS,

@@ -5,7 +5,7 @@
 // Kernels in this file
 //   helm_patch_kernel   n_basis 2-5, complex: one element per lane, lanes 0-31 u / 32-63 v; patches of 32 elements (one
 //                       wavefront) or, for affine plans, 64 (two wavefronts sharing the LDS copy)
-//   helm_lane_kernel    n_basis 3-4, complex, general geometry, large plans: lane = element, both components per lane,
+//   helm_lane_kernel    n_basis 2-4, complex, general geometry, large plans: lane = element, both components per lane,
 //                       64-element patches, one wavefront each
 //   op_patch_kernel     n_basis 2-5, real   : one element per lane, one patch of 64 elements per wavefront
 //   helm_mfma_kernel    n_basis 6-8, complex: batches of 16 elements, 1-D contractions on v_mfma_f64_16x16x4_f64
@@ -482,7 +482,7 @@ namespace
     // x is consumed when the registers are filled and the same array then accumulates y (as in helm_mfma_kernel); the
     // boundary-face term re-reads its few x values from global memory.
     template <int NB, int NQS, int NQM, bool NT>
-    __global__ void __launch_bounds__(64, (NB == 3 ? 3 : 2)) helm_lane_kernel(HelmArgs A, const double *__restrict__ PS, const double *__restrict__ DS,
+    __global__ void __launch_bounds__(64, (NB == 2 ? 5 : (NB == 3 ? 3 : 2))) helm_lane_kernel(HelmArgs A, const double *__restrict__ PS, const double *__restrict__ DS,
                                                               const double *__restrict__ PM, const double *__restrict__ PF)
     {
         constexpr int NN = NB * NB, NP = (NN + 1) / 2, PEK = 64;
@@ -953,7 +953,7 @@ namespace
     template <int NB, int NQS, int NQM>
     void launch_patch(const cuddh_helmholtz_plan *p, const HelmArgs &A, hipStream_t st)
     {
-        if constexpr (NB == 4 || NB == 3)
+        if constexpr (NB <= 4)
             if (p->pe == 64 && !p->Gu && p->lane_form)
             {
                 const size_t lds = (size_t)2 * p->max_loc * sizeof(double);
@@ -2266,9 +2266,10 @@ extern "C"
         // 1.95 M quads 817 -> 764 us; at 256^2 (half a round) it is 10 % slower, hence the size rule.  CUDDH_HELM_LANE=0/1 overrides.
         // n_basis 3 (151 VGPRs, 3 waves/SIMD): 1024^2 213 -> 185 us (4.75 TB/s), a wash at 512^2 where the plan fits the
         // infinity cache: from 8192 patches on.
-        bool lane_form = pe == PE && ((nb == 4 && n_elem >= 4096 * 64) || (nb == 3 && n_elem >= 8192 * 64));
+        // n_basis 2 (92 VGPRs, 5 waves/SIMD): 1024^2 124 -> 103 us, 2048^2 510 -> 418-438 us.
+        bool lane_form = pe == PE && ((nb == 4 && n_elem >= 4096 * 64) || (nb <= 3 && n_elem >= 8192 * 64));
         if (const char *e = std::getenv("CUDDH_HELM_LANE"))
-            lane_form = (nb == 4 || nb == 3) && pe == PE && std::atoi(e) == 1;
+            lane_form = nb <= 4 && pe == PE && std::atoi(e) == 1;
         if (lane_form)
             pe = 64;
         const int err = build_plan(out, ndof, n_elem, nb, h_I, h_xy, nqS, h_PS, h_DS, G_S, nqM, h_PM, a_M, n_faces, h_fI, h_face_elem, nqF,
