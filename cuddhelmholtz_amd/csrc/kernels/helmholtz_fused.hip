@@ -481,9 +481,11 @@ namespace
     // round trip of its chain; the price is twice the element state per lane (2 waves per SIMD instead of 3).  The LDS copy of
     // x is consumed when the registers are filled and the same array then accumulates y (as in helm_mfma_kernel); the
     // boundary-face term re-reads its few x values from global memory.
-    template <int NB, int NQS, int NQM, bool NT>
+    // UG: the stiffness metric is the same in every element and comes from the uniform table GU (scalar loads)
+    template <int NB, int NQS, int NQM, bool NT, bool UG>
     __global__ void __launch_bounds__(64, (NB == 2 ? 5 : (NB == 3 ? 3 : 2))) helm_lane_kernel(HelmArgs A, const double *__restrict__ PS, const double *__restrict__ DS,
-                                                              const double *__restrict__ PM, const double *__restrict__ PF)
+                                                              const double *__restrict__ PM, const double *__restrict__ PF,
+                                                              const double *__restrict__ GU)
     {
         constexpr int NN = NB * NB, NP = (NN + 1) / 2, PEK = 64;
         extern __shared__ double lds[];
@@ -507,14 +509,17 @@ namespace
         for (int j = 0; j < NP; ++j)
             lpk[j] = li[j * PEK];
         const int mycol = active ? A.colour[patch * PEK + lane] : -1;
-        double g_first[3 * NQS]; // first stiffness slice, requested before the gather
-#pragma unroll
-        for (int r = 0; r < NQS; ++r)
+        auto load_stiff = [&](int q, double (&g)[3 * NQS])
         {
-            g_first[3 * r + 0] = metric_load<NT>(&Gp[((0 * 3 + 0) * NQS + r) * PEK]);
-            g_first[3 * r + 1] = metric_load<NT>(&Gp[((0 * 3 + 1) * NQS + r) * PEK]);
-            g_first[3 * r + 2] = metric_load<NT>(&Gp[((0 * 3 + 2) * NQS + r) * PEK]);
-        }
+#pragma unroll
+            for (int r = 0; r < NQS; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    g[3 * r + c] = UG ? GU[(q * 3 + c) * NQS + r] : metric_load<NT>(&Gp[((q * 3 + c) * NQS + r) * PEK]);
+        };
+        double g_first[3 * NQS]; // first stiffness slice, requested before the gather
+        if constexpr (!UG)
+            load_stiff(0, g_first);
 
         constexpr int ROWS = 10; // 640 dofs per pass: an 8x8-element patch of n_basis 4 (625) in one
         for (int base = 0; base < nloc; base += 64 * ROWS)
@@ -648,18 +653,13 @@ namespace
             }
         };
 
-        stiff_slice(0, g_first);
+        if constexpr (!UG)
+            stiff_slice(0, g_first);
 #pragma unroll 1
-        for (int q = 1; q < NQS; ++q)
+        for (int q = UG ? 0 : 1; q < NQS; ++q)
         {
             double g[3 * NQS];
-#pragma unroll
-            for (int r = 0; r < NQS; ++r)
-            {
-                g[3 * r + 0] = metric_load<NT>(&Gp[((q * 3 + 0) * NQS + r) * PEK]);
-                g[3 * r + 1] = metric_load<NT>(&Gp[((q * 3 + 1) * NQS + r) * PEK]);
-                g[3 * r + 2] = metric_load<NT>(&Gp[((q * 3 + 2) * NQS + r) * PEK]);
-            }
+            load_stiff(q, g);
             stiff_slice(q, g);
         }
         // two mass slices per round trip: 2 x NQM values are no more registers than the 3 x NQS of a stiffness slice, which
@@ -954,14 +954,18 @@ namespace
     void launch_patch(const cuddh_helmholtz_plan *p, const HelmArgs &A, hipStream_t st)
     {
         if constexpr (NB <= 4)
-            if (p->pe == 64 && !p->Gu && p->lane_form)
+            if (p->pe == 64 && p->lane_form)
             {
                 const size_t lds = (size_t)2 * p->max_loc * sizeof(double);
                 const dim3 grid(8 * A.xcd_chunk), block(64);
-                if (p->streaming)
-                    hipLaunchKernelGGL((helm_lane_kernel<NB, NQS, NQM, true>), grid, block, lds, st, A, p->PS, p->DS, p->PM, p->PF);
+                if (p->Gu && p->streaming)
+                    hipLaunchKernelGGL((helm_lane_kernel<NB, NQS, NQM, true, true>), grid, block, lds, st, A, p->PS, p->DS, p->PM, p->PF, p->Gu);
+                else if (p->Gu)
+                    hipLaunchKernelGGL((helm_lane_kernel<NB, NQS, NQM, false, true>), grid, block, lds, st, A, p->PS, p->DS, p->PM, p->PF, p->Gu);
+                else if (p->streaming)
+                    hipLaunchKernelGGL((helm_lane_kernel<NB, NQS, NQM, true, false>), grid, block, lds, st, A, p->PS, p->DS, p->PM, p->PF, p->Gu);
                 else
-                    hipLaunchKernelGGL((helm_lane_kernel<NB, NQS, NQM, false>), grid, block, lds, st, A, p->PS, p->DS, p->PM, p->PF);
+                    hipLaunchKernelGGL((helm_lane_kernel<NB, NQS, NQM, false, false>), grid, block, lds, st, A, p->PS, p->DS, p->PM, p->PF, p->Gu);
                 return;
             }
         if (p->pe == 64)
@@ -2267,15 +2271,19 @@ extern "C"
         // n_basis 3 (151 VGPRs, 3 waves/SIMD): 1024^2 213 -> 185 us (4.75 TB/s), a wash at 512^2 where the plan fits the
         // infinity cache: from 8192 patches on.
         // n_basis 2 (92 VGPRs, 5 waves/SIMD): 1024^2 124 -> 103 us, 2048^2 510 -> 418-438 us.
-        bool lane_form = pe == PE && ((nb == 4 && n_elem >= 4096 * 64) || (nb <= 3 && n_elem >= 8192 * 64));
+        // Affine plans: only n_basis 2 gains from the lane form (1024^2: 80 -> 68 us); n_basis 3 loses (133 -> 154 us) and
+        // n_basis 4 loses a lot (311 -> 365 us: with no metric traffic the kernel lives on occupancy).
+        const bool affine_plan = pe == 64; // decided above
+        const bool affine_lane = affine_plan && nb == 2;
+        bool lane_form = (pe == PE && ((nb == 4 && n_elem >= 4096 * 64) || (nb <= 3 && n_elem >= 8192 * 64))) || (affine_lane && n_elem >= 8192 * 64);
         if (const char *e = std::getenv("CUDDH_HELM_LANE"))
-            lane_form = nb <= 4 && pe == PE && std::atoi(e) == 1;
+            lane_form = nb <= 4 && (pe == PE || affine_lane) && std::atoi(e) == 1;
         if (lane_form)
             pe = 64;
         const int err = build_plan(out, ndof, n_elem, nb, h_I, h_xy, nqS, h_PS, h_DS, G_S, nqM, h_PM, a_M, n_faces, h_fI, h_face_elem, nqF,
                                    h_PF, a_F, pe);
         if (!err && *out)
-            (*out)->lane_form = lane_form && !(*out)->Gu;
+            (*out)->lane_form = lane_form && (!(*out)->Gu || affine_lane);
         return err;
     }
 
