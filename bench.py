@@ -7,9 +7,17 @@ reading reference DDH supports), fp32 local solves (the reference's precision), 
 
   step   = one Arnoldi step of GMRES(20) on the substructured operator: one DDH::action
            (65,536 WaveHoltz subdomain solves, sharded over the ranks) + modified Gram-Schmidt
-           against the current Krylov basis (k cycles 0..19).  The once-per-20-steps restart
-           bookkeeping (host triangular solve, true-residual matvec) is not in the loop.
+           against the current Krylov basis (k cycles 0..19), issued through the same C-ABI calls
+           the product's gmres() makes (fused MGS stages, coefficients on the device).
   value  = 2 * g_ndof * steps / seconds   [DoF.iter/s], whole job, MAX time over ranks.
+  gmres_call = one REAL call of the product's gmres() (cuddh_gmres_ddh; with N > 1 the sharded
+           native Arnoldi with the all-reduce hook) on the same system, m = 20, one restart cycle,
+           tol 0: SURVEY 8d's definition 2 * g_ndof * num_matvec / t_gmres with num_matvec as the
+           solver counts it (initial residual + 20 Arnoldi steps + true residual = 22), restart
+           bookkeeping included.  Reported beside `value`; the two must agree to a few per cent.
+  --gpus N > 1 without a launcher environment: bench.py starts its N ranks itself
+           (python -m torch.distributed.run, fresh child processes, before anything touches the GPU)
+           and relays rank 0's line; it never prints an N = 1 number for an N > 1 request.
   N > 1  = subdomains split into contiguous ranges, one per rank (total work fixed -> "strong"
            scaling).  Default: trace/Krylov vectors partitioned by slot ownership, the traces a
            rank writes for another rank's subdomains go to that (neighbouring) rank by grouped
@@ -54,6 +62,40 @@ def ddh_flops_per_subdomain_step(nb: int, nel: int) -> float:
     return 2.0 * sweep + update
 
 
+def self_launch(n_gpus: int) -> int:
+    """`python bench.py --gpus N` (N > 1) outside a launcher: start the N ranks as fresh child processes through
+    torch.distributed.run and relay their output.  Runs before torch or the native library is imported in this process --
+    nothing here touches the GPU, and the process is never replaced (no exec)."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve()), *sys.argv[1:]]
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        try:
+            rec = json.loads(ln)
+        except ValueError:
+            print(ln, file=sys.stderr)
+            continue
+        if isinstance(rec, dict) and "metric" in rec:
+            line = rec
+    if proc.returncode != 0 or line is None:
+        print(f"bench.py: the {n_gpus}-rank run failed (exit code {proc.returncode}); no result line", file=sys.stderr)
+        return proc.returncode or 1
+    if line.get("n_gpus") != n_gpus:
+        print(f"bench.py: asked for {n_gpus} GPUs but the run reports n_gpus={line.get('n_gpus')}", file=sys.stderr)
+        return 1
+    print(json.dumps(line), flush=True)
+    return 0
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -72,8 +114,12 @@ def main() -> None:
                          "cuddhelmholtz_amd.dist.ShardedHelmholtz) and report its aggregate rate as `roofline_sharded`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-gmres-call", action="store_true", help="skip the real gmres() call timed beside the step loop")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))
 
     import torch
     import torch.distributed as dist
@@ -83,8 +129,11 @@ def main() -> None:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a {world}-rank number for a {args.gpus}-GPU request")
+    if world > 1 and not args.rehearse_gloo and torch.cuda.device_count() < world:
+        raise SystemExit(f"--gpus {world} but only {torch.cuda.device_count()} device(s) visible (one rank per GPU; "
+                         "--rehearse-gloo rehearses the host logic on one GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
     staged = args.rehearse_gloo
@@ -180,24 +229,39 @@ def main() -> None:
         allred(bb)
     V[0].copy_(b / torch.sqrt(bb))
 
+    ws_half = lib.cuddh_hip_reduce_ws_bytes() // 2  # the two partial-sum buffers of the fused MGS stages (src/krylov.cpp)
+    h_host = torch.zeros(gmres_m + 2, dtype=torch.float32).pin_memory()
+
     def arnoldi_step(k: int) -> None:
+        """One Arnoldi step exactly as the product's gmres() issues it (csrc/src/krylov.cpp, reference source/gmres.cpp:160-179)."""
         vk, vk1 = V[k], V[k + 1]
-        # w = (I - T) v_k : local solves of this rank's subdomains, then the trace exchange / reassembly
-        sh.traces(None, vk, upd)
-        N.check(lib.cuddh_hip_copy_f32(n, p(vk), p(vk1), st))
-        N.check(lib.cuddh_hip_axpby_f32(n, -1.0, p(upd), 1.0, p(vk1), st))
-        for j in range(k + 1):
-            N.check(lib.cuddh_hip_dot_f32(n, p(vk1), p(V[j]), p(hcol[j:]), p(ws), st))
-            if partitioned:  # the vectors are partitioned over the ranks: the coefficient is the sum of the local dots
-                allred(hcol[j:j + 1])
-            N.check(lib.cuddh_hip_axpby_dev_f32(n, -1.0, p(hcol[j:]), p(V[j]), 1.0, p(vk1), st))
+        if world == 1:
+            F.action(vk, vk1)  # DDH::action: local solves, then v_{k+1} = v_k - T v_k
+        else:
+            # local solves of this rank's subdomains, then the trace exchange / reassembly
+            sh.traces(None, vk, upd)
+            N.check(lib.cuddh_hip_copy_f32(n, p(vk), p(vk1), st))
+            N.check(lib.cuddh_hip_axpby_f32(n, -1.0, p(upd), 1.0, p(vk1), st))
         if partitioned:
+            # vectors partitioned over the ranks: every coefficient is the all-reduced sum of the local dots (MGS parity mode)
+            for j in range(k + 1):
+                N.check(lib.cuddh_hip_dot_f32(n, p(vk1), p(V[j]), p(hcol[j:]), p(ws), st))
+                allred(hcol[j:j + 1])
+                N.check(lib.cuddh_hip_axpby_dev_f32(n, -1.0, p(hcol[j:]), p(V[j]), 1.0, p(vk1), st))
             N.check(lib.cuddh_hip_dot_f32(n, p(vk1), p(vk1), p(hcol[k + 1:]), p(ws), st))
             allred(hcol[k + 1:k + 2])
             hcol[k + 1:k + 2].sqrt_()
+            N.check(lib.cuddh_hip_scal_inv_dev_f32(n, p(hcol[k + 1:]), p(vk1), st))
         else:
-            N.check(lib.cuddh_hip_nrm2_f32(n, p(vk1), p(hcol[k + 1:]), p(ws), st))
-        N.check(lib.cuddh_hip_scal_inv_dev_f32(n, p(hcol[k + 1:]), p(vk1), st))
+            # fused stages: stage j applies the projection on v_{j-1} and leaves the partial sums of <w, v_j> for stage j+1
+            pa, pb = ws.data_ptr(), ws.data_ptr() + ws_half
+            N.check(lib.cuddh_hip_mgs_stage_f32(n, p(vk1), None, p(V[0]), C.c_void_p(pa), C.c_void_p(pa), p(hcol), st))
+            for j in range(k + 1):
+                vnext = p(V[j + 1]) if j + 1 < k + 1 else None
+                N.check(lib.cuddh_hip_mgs_stage_f32(n, p(vk1), p(V[j]), vnext, C.c_void_p(pa), C.c_void_p(pb), p(hcol[j:]), st))
+                pa, pb = pb, pa
+            N.check(lib.cuddh_hip_mgs_finish_f32(n, p(vk1), C.c_void_p(pa), p(hcol[k + 1:]), st))
+        h_host[: k + 2].copy_(hcol[: k + 2])  # the Hessenberg column reaches the host once per step (Givens on the host)
         if k + 1 == gmres_m:  # restart: continue from the last basis vector
             V[0].copy_(vk1)
 
@@ -280,6 +344,34 @@ def main() -> None:
         },
     }
 
+    # ---------------------------------------------------------------- one real gmres() call (SURVEY 8d's definition of the metric)
+    if not args.no_gmres_call:
+        lam = torch.zeros(n, dtype=torch.float32, device=dev)
+        barrier()
+        t0 = time.perf_counter()
+        if world == 1:
+            out = cd.gmres(n, lam, F, b, gmres_m, 2, 0.0)  # cuddh_gmres_ddh: the call of examples/DDH.cpp:143
+        else:
+            def A_sh(xv, yv):
+                sh.traces(None, xv, upd)
+                torch.sub(xv, upd, out=yv)
+
+            out = cd.gmres(n, lam, A_sh, b, gmres_m, 2, 0.0, reduce=(lambda t: allred(t)) if partitioned else None)
+        barrier()
+        t_call = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([t_call], dtype=torch.float64, device=dev)
+            allred(tmax, dist.ReduceOp.MAX)
+            t_call = float(tmax.item())
+        result["gmres_call"] = {
+            "call": "cuddh::gmres(n_traces, lambda, &DDH, b, m=20, maxit=2, tol=0)" if world == 1 else
+                    "cuddh::gmres (native Arnoldi, callback operator = sharded DDH, ScalarReduce hook) m=20, maxit=2, tol=0",
+            "num_matvec": out.num_matvec, "num_iter": out.num_iter, "seconds": t_call,
+            "value": 2.0 * ndof * out.num_matvec / t_call, "unit": "DoF*iter/s",
+            "rel_residual_after_cycle": out.res_norm[-1] / out.res_norm[0],
+            "ratio_to_step_loop": (2.0 * ndof * out.num_matvec / t_call) / value,
+        }
+
     # ---------------------------------------------------------------- roofline: the global operator apply
     if rank == 0 and not args.no_roofline:
         result["roofline"] = helmholtz_roofline(cd, torch, dev, fem, mesh, omega, ndof)
@@ -301,6 +393,7 @@ def main() -> None:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
+        assert result["n_gpus"] == args.gpus
         print(json.dumps(result), flush=True)
 
 
@@ -366,27 +459,33 @@ def helmholtz_roofline(cd, torch, dev, fem, mesh, omega, ndof):
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) * 1e-3 / reps
 
-    # attainable HBM rate of this box, measured: a plain device copy through the product's own copy kernel
+    # streaming rates of this box, measured in this run on 1 GiB vectors through the product's own BLAS-1 kernels:
+    # a device copy (read + write bytes) and a read-only stream (nrm2).  They are reference points, not ceilings: the
+    # operator kernels are free to beat the copy kernel (and the real operators do).
     from cuddhelmholtz_amd import _native as N
 
-    n_copy = 1 << 27  # 1 GiB of doubles in, 1 GiB out
+    n_copy = 1 << 27  # 1 GiB of doubles
     src = torch.empty(n_copy, dtype=torch.float64, device=dev).fill_(1.0)
     dst = torch.empty_like(src)
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    ws = torch.zeros(N.lib.cuddh_hip_reduce_ws_bytes() // 8, dtype=torch.float64, device=dev)
+    res = torch.zeros(2, dtype=torch.float64, device=dev)
 
-    def copy_once():
-        N.check(N.lib.cuddh_hip_copy_f64(n_copy, C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), st))
+    def rate(fn, nbytes, reps=10):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        c0.record()
+        for _ in range(reps):
+            fn()
+        c1.record()
+        torch.cuda.synchronize()
+        return nbytes * reps / (c0.elapsed_time(c1) * 1e-3) / 1e9
 
-    for _ in range(3):
-        copy_once()
-    torch.cuda.synchronize()
-    c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    c0.record()
-    for _ in range(10):
-        copy_once()
-    c1.record()
-    torch.cuda.synchronize()
-    copy_gbs = 2.0 * 8.0 * n_copy * 10 / (c0.elapsed_time(c1) * 1e-3) / 1e9
+    vp = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    copy_gbs = rate(lambda: N.check(N.lib.cuddh_hip_copy_f64(n_copy, vp(src), vp(dst), st)), 2.0 * 8.0 * n_copy)
+    read_gbs = rate(lambda: N.check(N.lib.cuddh_hip_nrm2_f64(n_copy, vp(src), vp(res), vp(ws), st)), 8.0 * n_copy)
     del src, dst
 
     # the roofline figure is stated on the GENERAL-geometry layout: the plan is told not to exploit that a
@@ -412,7 +511,7 @@ def helmholtz_roofline(cd, torch, dev, fem, mesh, omega, ndof):
         torch.cuda.synchronize()
         ts = s0.elapsed_time(s1) * 1e-3 / 30
         bs = ne_ * (comps * nq * nq * 8 + nb_ * nb_ * 4) + ndof * 16
-        singles[name] = {"seconds_per_apply": ts, "algorithmic_bytes": bs, "achieved": bs / ts / 1e9, "unit": "GB/s",
+        singles[name] = {"kernel": op.kernel(), "seconds_per_apply": ts, "algorithmic_bytes": bs, "achieved": bs / ts / 1e9, "unit": "GB/s",
                          "frac": bs / ts / 1e9 / HBM_PEAK_GBS}
         del op
     os.environ["CUDDH_PLAN_AFFINE"] = "1"
@@ -430,30 +529,38 @@ def helmholtz_roofline(cd, torch, dev, fem, mesh, omega, ndof):
         os.environ["CUDDH_PLAN_AFFINE"] = prev
     b_alg = A.bytes_per_apply(False)
     gbs = b_alg / t / 1e9
-    # HBM traffic per apply from the PMC counters (collected in separate rocprofv3 --pmc passes and committed under
-    # profiles/; bench.py cannot run the profiler on itself): only quoted when it was measured for this very configuration
-    traffic = None
+    # HBM traffic per apply from the PMC counters: collected in separate rocprofv3 --pmc passes (bench.py cannot run the
+    # profiler on itself) by profiles/tools/pmc_traffic.sh and committed under profiles/rNN/helm_pmc_traffic.json.  It is
+    # quoted only when that record was taken for this mesh AND this kernel instantiation; `traffic_source` says where it
+    # comes from, so a stale record cannot pass for a measurement of this run.
+    traffic, traffic_source = None, "no committed PMC record for this mesh and kernel"
     nx_now = int(round(math.sqrt(mesh.n_elem())))
+    kernel_now = A.kernel()
     for pmc in sorted((ROOT / "profiles").glob("r*/helm_pmc_traffic.json"), reverse=True):
         rec = json.loads(pmc.read_text())
-        if rec.get("nx") == nx_now and rec.get("nb") == fem.basis.n:
+        if rec.get("nx") == nx_now and rec.get("nb") == fem.basis.n and rec.get("kernel") == kernel_now:
             traffic = rec["traffic_bytes_per_apply"]
+            traffic_source = {"file": str(pmc.relative_to(ROOT)), "kernel": rec["kernel"], "collected_at_commit": rec.get("commit"),
+                              "how": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 corrections as in "
+                                     "MI355X_MICROARCH.md; NOT measured in this run"}
             break
+    best_stream = max(copy_gbs, read_gbs)
     return {
         "bound": "hbm",
-        "kernel": (("helm_lane_kernel" if ((nb_ == 4 and ne_ >= 4096 * 64) or (nb_ <= 3 and ne_ >= 8192 * 64)) else "helm_patch_kernel" if nb_ <= 5 else "helm_mfma_kernel")
-                   + " + helm_border_kernel (fused complex Helmholtz apply)") if A.fused() else "unfused operator sequence",
+        "kernel": (kernel_now + " + helm_border_kernel (fused complex Helmholtz apply)") if A.fused() else "unfused operator sequence",
         "achieved": gbs,
         "peak": HBM_PEAK_GBS,
         "unit": "GB/s",
         "frac": gbs / HBM_PEAK_GBS,
-        "copy_ceiling": copy_gbs,  # measured in this run: device copy of 1 GiB, read + write bytes / time
-        "frac_of_copy_ceiling": gbs / copy_gbs,
         "traffic": traffic,
+        "traffic_source": traffic_source,
         "algorithmic_bytes": b_alg,
         "layout_bytes": A.bytes_per_apply(True),
         "seconds_per_apply": t,
         "complex_dof_per_s": ndof / t,
+        # measured in this run (GB/s): what plain streams reach on this box; reference points, not bounds
+        "measured_streams": {"device_copy_f64_1GiB": copy_gbs, "read_only_nrm2_f64_1GiB": read_gbs, "best": best_stream,
+                             "frac_of_best": gbs / best_stream},
         "affine": affine,
         "single_operators": singles,  # real vectors, general layout, y = Op x through the same plan machinery
     }

@@ -121,6 +121,7 @@ _sig("cuddh_hip_helmholtz_plan_create", ci, C.POINTER(vp), ci, ci, ci, vp, vp, c
 _sig("cuddh_hip_helmholtz_plan_destroy", ci, vp)
 _sig("cuddh_hip_helmholtz_apply", ci, vp, cd, vp, vp, vp)
 _sig("cuddh_hip_helmholtz_plan_bytes", cs, vp, ci)
+_sig("cuddh_hip_helmholtz_plan_describe", ci, vp, vp, ci)
 _sig("cuddh_hip_operator_plan_create", ci, C.POINTER(vp), ci, ci, ci, ci, vp, vp, ci, vp, vp, vp)
 _sig("cuddh_hip_operator_plan_apply", ci, vp, cd, ci, vp, vp, vp)
 _sig("cuddh_hip_ddh_geom_setup_f32", ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp)
@@ -128,6 +129,7 @@ _sig("cuddh_hip_ddh_geom_setup_f64", ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp)
 _sig("cuddh_hip_ddh_plan_create", ci, C.POINTER(vp), C.POINTER(DdhDesc), ci, ci)
 _sig("cuddh_hip_ddh_plan_destroy", ci, vp)
 _sig("cuddh_hip_ddh_plan_kernel", ci, vp)
+_sig("cuddh_hip_ddh_plan_set_wh_iters", ci, vp, ci)
 _sig("cuddh_hip_ddh_apply_f32", ci, vp, ci, ci, vp, vp, ci, vp, vp, vp)
 _sig("cuddh_hip_ddh_apply_f64", ci, vp, ci, ci, vp, vp, ci, vp, vp, vp)
 
@@ -179,6 +181,7 @@ _sig("cuddh_operator_apply", ci, vp, vp, vp)
 _sig("cuddh_operator_apply_add", ci, vp, cd, vp, vp)
 _sig("cuddh_helmholtz_apply_unfused", ci, vp, vp, vp)
 _sig("cuddh_helmholtz_is_fused", ci, vp)
+_sig("cuddh_operator_kernel_name", ci, vp, vp, ci)
 _sig("cuddh_helmholtz_bytes", cs, vp, ci)
 _sig("cuddh_linear_functional", ci, vp, ci, ci, cd, cd, ci, vp)
 _sig("cuddh_face_linear_functional", ci, vp, ci, ci, cd, cd, ci, vp)
@@ -187,6 +190,7 @@ _sig("cuddh_ddh_create", vp, cd, vp, vp, ci, ci, ci, ci)
 _sig("cuddh_ddh_destroy", None, vp)
 _sig("cuddh_ddh_size", ci, vp)
 _sig("cuddh_ddh_info", ci, vp, vp, vp)
+_sig("cuddh_ddh_set_wh_iters", ci, vp, ci)
 _sig("cuddh_ddh_rhs", ci, vp, vp, vp)
 _sig("cuddh_ddh_postprocess", ci, vp, vp, vp, vp)
 _sig("cuddh_ddh_action", ci, vp, vp, vp)

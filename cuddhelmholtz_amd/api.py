@@ -261,6 +261,13 @@ class _Operator:
             except Exception:  # noqa: BLE001
                 pass
 
+    def kernel(self) -> str:
+        """kernel instantiation action() launches, e.g. 'helm_lane_kernel<4,5,8,NT=1,UG=0> pe=64' (single operators build
+        their plan on the first action(): 'generic' before that and when no specialised kernel exists)"""
+        buf = C.create_string_buffer(160)
+        N.check_capi(lib.cuddh_operator_kernel_name(self._h, buf, 160), "kernel")
+        return buf.value.decode()
+
     def action(self, *args):
         if len(args) == 2:
             x, y = args
@@ -384,6 +391,10 @@ class DDH:
         out = dict(zip(keys, map(int, info)))
         out["dt"] = dt.value
         return out
+
+    def set_wh_iters(self, n: int = 5):
+        """Verification knob: WaveHoltz iterations per local solve (reference: 5, source/DDH.cpp:136)."""
+        N.check_capi(lib.cuddh_ddh_set_wh_iters(self._h, int(n)), "DDH.set_wh_iters")
 
     def table(self, name: str) -> np.ndarray:
         n = lib.cuddh_ddh_table(self._h, name.encode(), None, 1)

@@ -38,6 +38,9 @@ namespace cuddh
             int num_steps() const { return nt; }
             double time_step() const { return dt; }
             int kernel_kind() const;
+            /// WaveHoltz iterations per local solve; the reference hard-wires 5 (source/DDH.cpp:136), the default.
+            /// Verification knob (tests/test_ddh_physics.py), see cuddh_hip_ddh_plan_set_wh_iters.
+            void set_waveholtz_iterations(int n) const;
             const EnsembleSpace &ensemble() const { return *efem; }
 
             /// runs the local solves of subdomains [dom_begin, dom_end)

@@ -6,6 +6,7 @@
 #define CUDDH_AMD_HELMHOLTZ_HPP
 
 #include <cstddef>
+#include <string>
 
 #include "operator.hpp"
 #include "operators.hpp"
@@ -35,6 +36,8 @@ namespace cuddh
 
         /// true when the plan-based kernel is in use (false: fell back to the separate operators)
         bool fused() const { return plan != nullptr; }
+        /// kernel instantiation of the fused apply ("unfused" when it fell back to the separate operators)
+        std::string kernel_name() const;
 
         /// bytes per apply: algorithmic (SURVEY 8d formula) or as laid out by the plan
         std::size_t bytes_per_apply(bool actual) const;

@@ -7,6 +7,7 @@
 #define CUDDH_AMD_OPERATORS_HPP
 
 #include <cstddef>
+#include <string>
 
 #include "blas1.hpp"
 #include "memory.hpp"
@@ -34,6 +35,8 @@ namespace cuddh
                                             const double *d_metric) const;
             std::size_t bytes(bool actual) const;
             std::size_t bytes_affine() const;
+            /// kernel instantiation the plan launches ("generic" when there is no plan (yet))
+            std::string kernel_name() const;
 
         private:
             mutable cuddh_helmholtz_plan *plan = nullptr;
@@ -59,6 +62,8 @@ namespace cuddh
         const host_device_dvec &G() const { return _G; }
         /// bytes one action() moves through the patch plan (0 when the generic kernel is in use)
         std::size_t bytes_per_apply(bool actual = false) const { return plan.bytes(actual); }
+        /// kernel instantiation action() launches (after the first action(); "generic" = element_ops.hip)
+        std::string kernel_name() const { return plan.kernel_name(); }
 
     private:
         void setup(const QuadratureRule &quad);
@@ -85,6 +90,7 @@ namespace cuddh
         const host_device_dvec &P() const { return _P; }
         const host_device_dvec &weights() const { return _a; }
         std::size_t bytes_per_apply(bool actual = false) const { return plan.bytes(actual); }
+        std::string kernel_name() const { return plan.kernel_name(); }
 
     private:
         void setup(const double *a);

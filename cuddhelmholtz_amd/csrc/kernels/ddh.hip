@@ -28,18 +28,20 @@ struct cuddh_ddh_plan
     int kernel; // 1 block, 2 wave, 3 wave with hand-folded DPP FMAs (fp32), 4 = 3 + MFMA for the in-lane contractions,
                 // 5 dense element matrix on the matrix cores (fp32, uniform geometry)
     int nodes;  // nb*nb*nel1d*nel1d
+    int wh_iters = 5; // WaveHoltz iterations per local solve (source/DDH.cpp:136); WH_ITERS_REFERENCE
     float *Aop = nullptr; // kernel 5: element stiffness matrix as MFMA A operands, [4 k-steps][64 lanes]
     float *Sep = nullptr; // kernel 7: [Ax | Ay | beta | gamma] of the separable nb = 8 sweep
 };
 
 namespace
 {
-    constexpr int WH_ITERS = 5; // WaveHoltz iterations (source/DDH.cpp:136)
+    constexpr int WH_ITERS_REFERENCE = 5; // WaveHoltz iterations of the reference (source/DDH.cpp:136)
 
     template <typename Real>
     struct DdhArgs
     {
         int g_ndof, n_lambda, nt, mx_dof, mx_fdof, nodes, dom_begin, dom_end;
+        int wh_iters; // 5 unless a verification run changed it (cuddh_hip_ddh_plan_set_wh_iters)
         Real omega, dt;
         const int *s_dof, *s_fdof, *B, *gI, *sI;
         const Real *G, *m, *gmi, *a, *H;
@@ -317,7 +319,7 @@ namespace
         const Real dt = A.dt, half_dt = Real(0.5) * A.dt;
         const int nt = A.nt;
 
-        for (int whit = 0; whit < WH_ITERS; ++whit)
+        for (int whit = 0; whit < A.wh_iters; ++whit)
         {
             {
                 const Real k0 = filt[0];
@@ -718,7 +720,7 @@ namespace
         const Real dt = A.dt, half_dt = Real(0.5) * A.dt;
         const int nt = A.nt;
 
-        for (int whit = 0; whit < WH_ITERS; ++whit)
+        for (int whit = 0; whit < A.wh_iters; ++whit)
         {
             {
                 const Real k0 = filt[0];
@@ -901,7 +903,7 @@ namespace
 
         const float dt = A.dt, half_dt = 0.5f * A.dt;
         const int nt = A.nt;
-        for (int whit = 0; whit < WH_ITERS; ++whit)
+        for (int whit = 0; whit < A.wh_iters; ++whit)
         {
             {
                 const float k0 = filt[0];
@@ -1145,7 +1147,7 @@ namespace
 
         const Real dt = A.dt, half_dt = Real(0.5) * A.dt;
         const int nt = A.nt;
-        for (int whit = 0; whit < WH_ITERS; ++whit)
+        for (int whit = 0; whit < A.wh_iters; ++whit)
         {
             const Real k0 = filt[0];
             p = u;
@@ -1409,6 +1411,7 @@ namespace
         A.g_ndof = d.g_ndof;
         A.n_lambda = d.n_lambda;
         A.nt = d.nt;
+        A.wh_iters = plan->wh_iters;
         A.mx_dof = d.mx_dof;
         A.mx_fdof = d.mx_fdof;
         A.nodes = plan->nodes;
@@ -1625,6 +1628,14 @@ extern "C"
     }
 
     int cuddh_hip_ddh_plan_kernel(const cuddh_ddh_plan *plan) { return plan ? plan->kernel : 0; }
+
+    int cuddh_hip_ddh_plan_set_wh_iters(cuddh_ddh_plan *plan, int wh_iters)
+    {
+        if (!plan || wh_iters < 0)
+            return static_cast<int>(hipErrorInvalidValue);
+        plan->wh_iters = wh_iters == 0 ? WH_ITERS_REFERENCE : wh_iters;
+        return 0;
+    }
 
     int cuddh_hip_ddh_apply_f32(const cuddh_ddh_plan *plan, int dom_begin, int dom_end, const double *x, double *y, int zero_y,
                                 const float *lambda, float *update, void *stream)

@@ -27,6 +27,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -2399,6 +2400,30 @@ extern "C"
             err = launch_status();
         }
         return err;
+    }
+
+    int cuddh_hip_helmholtz_plan_describe(const cuddh_helmholtz_plan *p, char *buf, int cap)
+    {
+        if (!p || !buf || cap <= 0)
+            return static_cast<int>(hipErrorInvalidValue);
+        // mirrors the dispatch of cuddh_hip_helmholtz_apply / cuddh_hip_operator_plan_apply above
+        const bool fused = p->nqS > 0 && p->nqM > 0;
+        const int kind = p->nqS > 0 ? 0 : 1, nq = kind == 0 ? p->nqS : p->nqM;
+        const bool nt = p->streaming != 0;
+        if (fused && p->Gm && p->Am)
+            std::snprintf(buf, cap, "helm_mfma_kernel<%d,%d,%d> pe=16 affine=%d", p->nb, p->nqS, p->nqM, p->gm_stride == 0 ? 1 : 0);
+        else if (fused && p->nb <= 4 && p->pe == 64 && p->lane_form)
+            std::snprintf(buf, cap, "helm_lane_kernel<%d,%d,%d,NT=%d,UG=%d> pe=64", p->nb, p->nqS, p->nqM, nt, p->Gu ? 1 : 0);
+        else if (fused)
+            std::snprintf(buf, cap, "helm_patch_kernel<%d,%d,%d,NT=%d,UG=%d,PEK=%d> pe=%d", p->nb, p->nqS, p->nqM, nt, p->Gu ? 1 : 0, p->pe, p->pe);
+        else if (p->Gm || p->Am)
+            std::snprintf(buf, cap, "op_mfma_kernel<%d,%d,%d> pe=16 affine=%d", p->nb, nq, kind, (kind == 0 ? p->gm_stride : p->am_stride) == 0 ? 1 : 0);
+        else
+        {
+            const bool mu = kind == 0 ? p->Gu != nullptr : p->au != nullptr;
+            std::snprintf(buf, cap, "op_patch_kernel<%d,%d,%d,NT=%d,UG=%d,PEK=%d> pe=%d", p->nb, nq, kind, (!mu && nt) ? 1 : 0, mu ? 1 : 0, p->pe, p->pe);
+        }
+        return 0;
     }
 
     size_t cuddh_hip_helmholtz_plan_bytes(const cuddh_helmholtz_plan *p, int actual)

@@ -1,6 +1,7 @@
 // C handle layer (include/cuddh_capi.h).  Compiled as HIP: the built-in integrands
 // are device functors fed to the LinearFunctional header templates.
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 #include <exception>
 #include <memory>
@@ -461,6 +462,21 @@ extern "C"
         auto *h = static_cast<OpHandle *>(op);
         return h->helm && h->helm->fused() ? 1 : 0;
     }
+    int cuddh_operator_kernel_name(void *op, char *buf, int cap)
+    {
+        return guarded([&]
+        {
+            auto *h = static_cast<OpHandle *>(op);
+            std::string name = "generic";
+            if (h->helm)
+                name = h->helm->kernel_name();
+            else if (auto *s = dynamic_cast<StiffnessMatrix *>(h->op.get()))
+                name = s->kernel_name();
+            else if (auto *m = dynamic_cast<MassMatrix *>(h->op.get()))
+                name = m->kernel_name();
+            std::snprintf(buf, cap, "%s", name.c_str());
+        });
+    }
     size_t cuddh_helmholtz_bytes(void *op, int actual)
     {
         auto *h = static_cast<OpHandle *>(op);
@@ -574,6 +590,17 @@ extern "C"
             else
                 fill(h->f32->internals());
             info[7] = h->is64() ? 1 : 0;
+        });
+    }
+    int cuddh_ddh_set_wh_iters(void *d, int n)
+    {
+        return guarded([&]
+        {
+            auto *h = static_cast<DdhHandle *>(d);
+            if (h->is64())
+                h->f64->internals().set_waveholtz_iterations(n);
+            else
+                h->f32->internals().set_waveholtz_iterations(n);
         });
     }
     int cuddh_ddh_rhs(void *d, const double *f, void *b)

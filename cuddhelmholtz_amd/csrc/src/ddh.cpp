@@ -306,6 +306,13 @@ namespace cuddh
         }
 
         template <typename Real>
+        void DDHCore<Real>::set_waveholtz_iterations(int n) const
+        {
+            ensure_plan();
+            check_hip(cuddh_hip_ddh_plan_set_wh_iters(plan, n), "DDH WaveHoltz iterations");
+        }
+
+        template <typename Real>
         void DDHCore<Real>::solve(int d0, int d1, const double *x, double *y, bool zero_y, const Real *lambda, Real *update) const
         {
             ensure_plan();

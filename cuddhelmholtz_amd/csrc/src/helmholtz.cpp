@@ -89,6 +89,14 @@ namespace cuddh
         scal(ndof, -1.0, Av);
     }
 
+    std::string HelmholtzOperator::kernel_name() const
+    {
+        char buf[128] = "unfused";
+        if (plan)
+            cuddh_hip_helmholtz_plan_describe(plan, buf, sizeof buf);
+        return buf;
+    }
+
     std::size_t HelmholtzOperator::bytes_affine() const { return cuddh_hip_helmholtz_plan_bytes(plan, 2); }
 
     std::size_t HelmholtzOperator::bytes_per_apply(bool actual) const

@@ -43,6 +43,13 @@ namespace cuddh
 
         std::size_t OperatorPlan::bytes(bool actual) const { return cuddh_hip_helmholtz_plan_bytes(plan, actual ? 1 : 0); }
         std::size_t OperatorPlan::bytes_affine() const { return cuddh_hip_helmholtz_plan_bytes(plan, 2); }
+        std::string OperatorPlan::kernel_name() const
+        {
+            char buf[128] = "generic";
+            if (plan)
+                cuddh_hip_helmholtz_plan_describe(plan, buf, sizeof buf);
+            return buf;
+        }
     } // namespace detail
 
     namespace

@@ -83,6 +83,8 @@ int cuddh_operator_apply(void *op, const double *x, double *y);               /*
 int cuddh_operator_apply_add(void *op, double c, const double *x, double *y); /* y += c A x */
 int cuddh_helmholtz_apply_unfused(void *op, const double *x, double *y);
 int cuddh_helmholtz_is_fused(void *op);
+/* kernel instantiation the operator's action() launches (Helmholtz, Stiffness, Mass; "generic"/"unfused" otherwise) */
+int cuddh_operator_kernel_name(void *op, char *buf, int cap);
 size_t cuddh_helmholtz_bytes(void *op, int actual); /* actual: 0 / 1 / 2 as cuddh_hip_helmholtz_plan_bytes */
 
 /* ---- load vectors with built-in integrands (device lambdas cannot cross a C ABI).
@@ -104,6 +106,8 @@ void cuddh_ddh_destroy(void *ddh);
 int cuddh_ddh_size(void *ddh);
 /* h_info = {n_domains, nt, n_lambda, mx_dof, mx_fdof, nel1d, kernel (needs a GPU; -1 if none), is_f64}; *h_dt = time step */
 int cuddh_ddh_info(void *ddh, int *h_info, double *h_dt);
+/* verification knob: WaveHoltz iterations per local solve (reference: 5, source/DDH.cpp:136; 0 restores it) */
+int cuddh_ddh_set_wh_iters(void *ddh, int n);
 /* traces are float for f64 == 0 and double otherwise */
 int cuddh_ddh_rhs(void *ddh, const double *f, void *b);
 int cuddh_ddh_postprocess(void *ddh, const void *lambda, const double *f, double *u);

@@ -153,6 +153,9 @@ int cuddh_hip_helmholtz_apply(const cuddh_helmholtz_plan *plan, double omega, co
  * meshes: one copy read through scalar loads instead of one per element; 0 otherwise).  CUDDH_PLAN_AFFINE=0 in the
  * environment at plan creation keeps the general form (used to measure the general-geometry roofline on a uniform mesh). */
 size_t cuddh_hip_helmholtz_plan_bytes(const cuddh_helmholtz_plan *plan, int actual);
+/* which kernel instantiation the plan's apply launches, e.g. "helm_lane_kernel<4,5,8,NT=1,UG=0> pe=64" (tests assert
+ * the form they mean to exercise; bench.py reports it instead of re-deriving the size rules) */
+int cuddh_hip_helmholtz_plan_describe(const cuddh_helmholtz_plan *plan, char *buf, int cap);
 
 /* The same plan machinery for ONE real operator -- the bandwidth path of StiffnessMatrix::action
  * (source/StiffnessMatrix.cpp:186-205, kind 0, metric = G (3,nq,nq,n_elem)) and MassMatrix::action
@@ -226,6 +229,11 @@ int cuddh_hip_ddh_plan_create(cuddh_ddh_plan **plan, const cuddh_ddh_desc *desc,
 int cuddh_hip_ddh_plan_destroy(cuddh_ddh_plan *plan);
 /* which kernel the plan resolved to (1..7) */
 int cuddh_hip_ddh_plan_kernel(const cuddh_ddh_plan *plan);
+/* WaveHoltz iterations per local solve.  The reference hard-wires 5 (`constexpr int wh_maxit = 5`,
+ * source/DDH.cpp:136) and that is the default; 0 restores it.  A verification knob: with more iterations the local
+ * solves become exact and DDH converges to the Helmholtz system its transmission conditions imply
+ * (tests/test_ddh_physics.py); production callers never touch it. */
+int cuddh_hip_ddh_plan_set_wh_iters(cuddh_ddh_plan *plan, int wh_iters);
 
 /* source/DDH.cpp:111-321 (ddh_action + stiffness).  x: forcing [F;G] (2*g_ndof
  * doubles) or NULL; y: solution output [u;v] (2*g_ndof doubles, zero-filled by

@@ -303,6 +303,11 @@ class DDH:
         return self.solve(x=f, want_y=True, lam=lam, want_update=False)[0]
 
 
+def ddh_set_wh_iters(n: int = 5):
+    """WaveHoltz iterations of every later DDH solve (5 = the reference, source/DDH.cpp:136)."""
+    lib().orc_ddh_set_wh_iters(C.c_int(n))
+
+
 # ------------------------------------------------------------------ GMRES
 def gmres(A, b, x0=None, m=20, maxit=100, tol=1e-6, dtype=np.float64, allreduce=None):
     """source/gmres.cpp:91-235 with numpy vectors of `dtype`; A(x) -> A x.  Returns (x, info).

@@ -67,9 +67,13 @@ def test_gpu_operators_match_golden(cuda, tag, kind, nb, omega):
     assert rel(Y.cpu().numpy(), G[f"{tag}_Ax"]) < 1e-12
 
 
+# kernels 5 and 7 exist in fp32 only (matrix-core / separable forms); fp32 results are held to the reference-precision
+# tolerance of tests/test_gpu_parity.py (2e-4 against the fp64 golden vectors), fp64 ones to 1e-10
 @pytest.mark.gpu
-@pytest.mark.parametrize("tag,kernel", [("ddh_8_4", 1), ("ddh_8_4", 2), ("ddh_8_4", 3), ("ddh_8_4", 4), ("ddh_8_8", 1)])
-def test_gpu_ddh_matches_golden(cuda, tag, kernel):
+@pytest.mark.parametrize("tag,kernel,precision", [("ddh_8_4", 1, "f64"), ("ddh_8_4", 2, "f64"), ("ddh_8_4", 3, "f64"), ("ddh_8_4", 4, "f64"),
+                                                  ("ddh_8_4", 3, "f32"), ("ddh_8_4", 4, "f32"), ("ddh_8_4", 5, "f32"),
+                                                  ("ddh_8_8", 1, "f64"), ("ddh_8_8", 6, "f64"), ("ddh_8_8", 6, "f32"), ("ddh_8_8", 7, "f32")])
+def test_gpu_ddh_matches_golden(cuda, tag, kernel, precision):
     import torch
 
     import cuddhelmholtz_amd as cd
@@ -77,17 +81,23 @@ def test_gpu_ddh_matches_golden(cuda, tag, kernel):
     nx, nb = int(G[f"{tag}_meta"][0]), int(G[f"{tag}_meta"][1])
     omega = float(G[f"{tag}_omega_dt"][0])
     fem = cd.H1Space(cd.Mesh2D.uniform_rect(nx, -1.0, 1.0, nx, -1.0, 1.0), cd.Basis(nb))
-    F = cd.DDH(omega, G[f"{tag}_h_a"], fem, nx, nx, precision="f64", kernel=kernel)
+    F = cd.DDH(omega, G[f"{tag}_h_a"], fem, nx, nx, precision=precision, kernel=kernel)
     info = F.info()
+    assert info["kernel"] == kernel  # (3 and 4 asked for in fp64 run kernel 2's generic DPP reads under their own number)
+    tol = 1e-10 if precision == "f64" else 2e-4
     assert (info["n_domains"], info["n_lambda"], info["nt"]) == tuple(int(v) for v in G[f"{tag}_meta"][2:])
     assert abs(info["dt"] - float(G[f"{tag}_omega_dt"][1])) < 1e-18
     f = torch.from_numpy(G[f"{tag}_f"]).to(cuda)
-    b = torch.zeros(F.size(), dtype=torch.float64, device=cuda)
+    b = torch.zeros(F.size(), dtype=F.trace_dtype, device=cuda)
     F.rhs(f, b)
-    assert rel(b.cpu().numpy(), G[f"{tag}_b"]) < 1e-10
+    e_b = rel(b.cpu().numpy(), G[f"{tag}_b"])
+    # T applied to the GOLDEN b, so that the three comparisons are independent of each other
+    bg = torch.from_numpy(G[f"{tag}_b"]).to(cuda).to(F.trace_dtype)
     Tb = torch.zeros_like(b)
-    F.local_traces(0, info["n_domains"], None, b, Tb)
-    assert rel(Tb.cpu().numpy(), G[f"{tag}_Tb"]) < 1e-10
+    F.local_traces(0, info["n_domains"], None, bg, Tb)
+    e_T = rel(Tb.cpu().numpy(), G[f"{tag}_Tb"])
     u = torch.zeros(2 * fem.size(), dtype=torch.float64, device=cuda)
-    F.postprocess(b, f, u)
-    assert rel(u.cpu().numpy(), G[f"{tag}_u"]) < 1e-10
+    F.postprocess(bg, f, u)
+    e_u = rel(u.cpu().numpy(), G[f"{tag}_u"])
+    print(f"golden {tag} kernel {info['kernel']} {precision}: rhs {e_b:.2e}, T b {e_T:.2e}, postprocess {e_u:.2e}")
+    assert max(e_b, e_T, e_u) < tol

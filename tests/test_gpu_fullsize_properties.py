@@ -21,6 +21,100 @@ def big(cuda):
     return dict(cd=cd, torch=torch, nx=nx, nb=nb, mesh=mesh, fem=fem, n=fem.size())
 
 
+def test_config2_properties_256(cuda):
+    """BASELINE config 2 (Helmholtz omega = 8 pi, 256 x 256 quads, GMRES(20) on the Stiffness/Mass/FaceMass composite): the
+    invariants of the full-size tests on config 2's own mesh for n_basis 4 (Basis(p) reading of p = 3 + 1) and
+    n_basis 3, and a GMRES(20) cycle on the fused operator that must reduce the residual exactly like the unfused one."""
+    import torch
+
+    import cuddhelmholtz_amd as cd
+
+    nx, omega = 256, 8 * math.pi
+    mesh = cd.Mesh2D.uniform_rect(nx, -1.0, 1.0, nx, -1.0, 1.0)
+    for nb, ndof in ((4, 591361), (3, 263169)):
+        fem = cd.H1Space(mesh, cd.Basis(nb))
+        n = fem.size()
+        assert n == ndof  # SURVEY 8d sizes
+        fs = cd.FaceSpace(fem, mesh.boundary_edges())
+        g = torch.Generator(device="cpu").manual_seed(256 + nb)
+        a2 = (0.5 + torch.rand(n, generator=g, dtype=torch.float64)).to(cuda)
+        ax = (0.5 + torch.rand(fs.size(), generator=g, dtype=torch.float64)).to(cuda)
+        A = cd.HelmholtzOperator(omega, a2, ax, fem, fs)
+        assert A.fused()
+        if nb == 4:
+            assert abs(A.bytes_per_apply() - 96.0e6) < 0.2e6  # SURVEY 8d: 96.0 MB per complex apply
+        x = (2 * torch.rand(2 * n, generator=g, dtype=torch.float64) - 1).to(cuda)
+        z = (2 * torch.rand(2 * n, generator=g, dtype=torch.float64) - 1).to(cuda)
+        Ax, Az, Axz, Ax2, U = (torch.empty_like(x) for _ in range(5))
+        A.action(x, Ax)
+        A.action(z, Az)
+        A.action(x, Ax2)
+        assert torch.equal(Ax, Ax2)
+        A.action(0.25 * x + 3.0 * z, Axz)
+        lin = 0.25 * Ax + 3.0 * Az
+        assert float(torch.linalg.norm(Axz - lin) / torch.linalg.norm(lin)) < 1e-13
+        s1, s2 = float(torch.dot(z, Ax)), float(torch.dot(x, Az))
+        assert abs(s1 - s2) <= 1e-11 * max(abs(s1), abs(s2))
+        A.action_unfused(x, U)
+        assert float(torch.linalg.norm(U - Ax) / torch.linalg.norm(Ax)) < 1e-13
+        # two GMRES(20) cycles: fused operator vs the composite of the separate operators through the callback path
+        b = Ax
+        xs1, xs2 = torch.zeros_like(b), torch.zeros_like(b)
+        o1 = cd.gmres(2 * n, xs1, A, b, 20, 3, 1e-12)
+        o2 = cd.gmres(2 * n, xs2, lambda p, q: A.action_unfused(p, q), b, 20, 3, 1e-12)
+        assert o1.num_matvec == o2.num_matvec == 43
+        assert o1.res_norm[-1] < o1.res_norm[0]
+        assert abs(o1.res_norm[-1] - o2.res_norm[-1]) <= 1e-9 * o1.res_norm[0]
+        assert float(torch.linalg.norm(xs1 - xs2) / torch.linalg.norm(xs1)) < 1e-9
+
+
+@pytest.mark.parametrize("nb,affine", [(2, "0"), (3, "0"), (2, "1")])
+def test_lane_form_chosen_by_size_nb2_nb3(cuda, nb, affine, monkeypatch):
+    """768 x 768 elements (589,824 >= the 8192 x 64 of the size rule): the plan must pick helm_lane_kernel with non-temporal
+    metric loads by itself for n_basis 2 and 3 (general layout) and for the affine n_basis-2 form; linearity, symmetry,
+    determinism, and agreement with the 32-element-patch kernel it replaces (CUDDH_HELM_LANE=0)."""
+    import torch
+
+    import cuddhelmholtz_amd as cd
+
+    nx, omega = 768, 24 * math.pi
+    monkeypatch.setenv("CUDDH_PLAN_AFFINE", affine)
+    for k in ("CUDDH_HELM_LANE", "CUDDH_HELM_PE", "CUDDH_PLAN_STREAMING"):
+        monkeypatch.delenv(k, raising=False)
+    mesh = cd.Mesh2D.uniform_rect(nx, -1.0, 1.0, nx, -1.0, 1.0)
+    fem = cd.H1Space(mesh, cd.Basis(nb))
+    n = fem.size()
+    fs = cd.FaceSpace(fem, mesh.boundary_edges())
+    g = torch.Generator(device="cpu").manual_seed(768 + nb)
+    a2 = (0.5 + torch.rand(n, generator=g, dtype=torch.float64)).to(cuda)
+    ax = (0.5 + torch.rand(fs.size(), generator=g, dtype=torch.float64)).to(cuda)
+    A = cd.HelmholtzOperator(omega, a2, ax, fem, fs)
+    nqS, nqM = nb + 1, 2 + 3 * nb // 2
+    # affine n_basis 2 moves ~100 MB per apply (fits the infinity cache: default load policy), the general layouts stream
+    assert A.kernel() in (f"helm_lane_kernel<{nb},{nqS},{nqM},NT=1,UG={affine}> pe=64", f"helm_lane_kernel<{nb},{nqS},{nqM},NT=0,UG={affine}> pe=64"), A.kernel()
+    if affine == "0":
+        assert "NT=1" in A.kernel()
+    x = (2 * torch.rand(2 * n, generator=g, dtype=torch.float64) - 1).to(cuda)
+    z = (2 * torch.rand(2 * n, generator=g, dtype=torch.float64) - 1).to(cuda)
+    Ax, Az, Axz, Ax2 = (torch.empty_like(x) for _ in range(4))
+    A.action(x, Ax)
+    A.action(z, Az)
+    A.action(x, Ax2)
+    assert torch.equal(Ax, Ax2)
+    A.action(0.5 * x - 2.0 * z, Axz)
+    lin = 0.5 * Ax - 2.0 * Az
+    assert float(torch.linalg.norm(Axz - lin) / torch.linalg.norm(lin)) < 1e-13
+    s1, s2 = float(torch.dot(z, Ax)), float(torch.dot(x, Az))
+    assert abs(s1 - s2) <= 1e-11 * max(abs(s1), abs(s2))
+    monkeypatch.setenv("CUDDH_HELM_LANE", "0")
+    P = cd.HelmholtzOperator(omega, a2, ax, fem, fs)
+    assert P.kernel().startswith(f"helm_patch_kernel<{nb},"), P.kernel()
+    P.action(x, Ax2)
+    assert float(torch.linalg.norm(Ax2 - Ax) / torch.linalg.norm(Ax)) < 1e-13
+    A.action_unfused(x, Ax2)
+    assert float(torch.linalg.norm(Ax2 - Ax) / torch.linalg.norm(Ax)) < 1e-13
+
+
 def test_operator_invariants_at_full_size(cuda, big):
     cd, torch, fem, n = big["cd"], big["torch"], big["fem"], big["n"]
     one = torch.ones(n, dtype=torch.float64, device=cuda)
@@ -64,6 +158,7 @@ def test_fused_helmholtz_linearity_symmetry_determinism_at_full_size(cuda, big, 
     ax = torch.ones(fs.size(), dtype=torch.float64, device=cuda)
     A = cd.HelmholtzOperator(omega, a2, ax, fem, fs)
     assert A.fused()
+    assert A.kernel() == "helm_lane_kernel<4,5,8,NT=1,UG=0> pe=64"  # what bench.py's roofline figure runs
     assert A.bytes_per_apply() == 1535639584  # 1,535 MB at 1024^2, n_basis 4
     g = torch.Generator(device="cpu").manual_seed(12345)
     x = (2 * torch.rand(2 * n, generator=g, dtype=torch.float64) - 1).to(cuda)

@@ -329,9 +329,12 @@ def test_affine_and_general_plans_agree(cuda, nb, monkeypatch):
 @pytest.mark.parametrize("nb", [2, 3, 4, 5])
 def test_patch_sizes_agree(cuda, kind, nx, nb, monkeypatch):
     """The plan kernels exist for 32- and 64-element patches (real operators: 64 by default; fused apply: 64 for affine
-    plans and, through helm_lane_kernel, for large n_basis-4 plans on general geometry, 32 otherwise).  CUDDH_OP_PE /
-    CUDDH_HELM_PE / CUDDH_HELM_LANE force a form; every combination must match the oracle and the results must agree to
-    rounding (the summation order inside a patch differs)."""
+    plans and, through helm_lane_kernel, for large plans on general geometry, 32 otherwise), each with and without the
+    non-temporal metric loads large plans use (NT template flag, chosen by plan size; CUDDH_PLAN_STREAMING forces it) and
+    with per-element or uniform (UG) metrics.  CUDDH_OP_PE / CUDDH_HELM_PE / CUDDH_HELM_LANE force a form; every
+    combination must run the kernel instantiation it is meant to (asserted through kernel()), match the oracle, and agree
+    with the others to rounding (the summation order inside a patch differs).  This is how the instantiations the 1024^2
+    benchmark uses (lane form + NT) are checked against the oracle on meshes the oracle can handle."""
     import torch
 
     import cuddhelmholtz_amd as cd
@@ -348,41 +351,63 @@ def test_patch_sizes_agree(cuda, kind, nx, nb, monkeypatch):
     refS = oracle.Stiffness(d).apply(xh[: d.ndof])
     refM = oracle.Mass(d, a2).apply(xh[: d.ndof])
     refA = oracle.helmholtz_apply(d, oracle.Stiffness(d), oracle.Mass(d, a2), oracle.FaceMass(ofs, ax), ofs, omega, xh)
-    got = {}
-    for pe in ("32", "64", "lane"):  # "lane": helm_lane_kernel (n_basis 4, general geometry; chosen by size otherwise)
+    nqS, nqM = nb + 1, 2 + 3 * nb // 2
+    got, seen = {}, set()
+    for pe in ("32", "64", "lane"):  # "lane": helm_lane_kernel (n_basis <= 4; chosen by size otherwise)
         for affine in ("1", "0"):
-            if pe == "lane":
-                monkeypatch.setenv("CUDDH_OP_PE", "64")
-                monkeypatch.delenv("CUDDH_HELM_PE", raising=False)
-                monkeypatch.setenv("CUDDH_HELM_LANE", "1")
-            else:
-                monkeypatch.setenv("CUDDH_OP_PE", pe)
-                monkeypatch.setenv("CUDDH_HELM_PE", pe)
-                monkeypatch.setenv("CUDDH_HELM_LANE", "0")
-            monkeypatch.setenv("CUDDH_PLAN_AFFINE", affine)
-            fem = cd.H1Space(pm, cd.Basis(nb))
-            fs = cd.FaceSpace(fem, faces)
-            x = to_dev(torch, xh, cuda)
-            a2d = to_dev(torch, a2, cuda)
-            yS = torch.full((d.ndof,), -2.0, dtype=torch.float64, device=cuda)
-            yM = torch.full((d.ndof,), -2.0, dtype=torch.float64, device=cuda)
-            cd.StiffnessMatrix(fem).action(x[: d.ndof], yS)
-            cd.MassMatrix(fem, a2d).action(x[: d.ndof], yM)
-            A = cd.HelmholtzOperator(omega, a2d, to_dev(torch, ax, cuda), fem, fs)
-            y = torch.empty(2 * d.ndof, dtype=torch.float64, device=cuda)
-            A.action(x, y)
-            assert A.fused()
-            assert rel(yS.cpu().numpy(), refS) < 1e-12 and rel(yM.cpu().numpy(), refM) < 1e-12
-            assert rel(y.cpu().numpy(), refA) < 1e-12
-            # accumulate form: y <- y + c Op x
-            yS2 = to_dev(torch, refS, cuda).clone()
-            cd.StiffnessMatrix(fem).action(-1.0, x[: d.ndof], yS2)
-            assert float(yS2.abs().max()) < 1e-11 * float(np.abs(refS).max())
-            got[(pe, affine)] = (yS.cpu().numpy(), yM.cpu().numpy(), y.cpu().numpy())
-    base = got[("32", "0")]
+            for nt in ("0", "1"):
+                if pe == "lane":
+                    monkeypatch.setenv("CUDDH_OP_PE", "64")
+                    monkeypatch.delenv("CUDDH_HELM_PE", raising=False)
+                    monkeypatch.setenv("CUDDH_HELM_LANE", "1")
+                else:
+                    monkeypatch.setenv("CUDDH_OP_PE", pe)
+                    monkeypatch.setenv("CUDDH_HELM_PE", pe)
+                    monkeypatch.setenv("CUDDH_HELM_LANE", "0")
+                monkeypatch.setenv("CUDDH_PLAN_AFFINE", affine)
+                monkeypatch.setenv("CUDDH_PLAN_STREAMING", nt)
+                fem = cd.H1Space(pm, cd.Basis(nb))
+                fs = cd.FaceSpace(fem, faces)
+                x = to_dev(torch, xh, cuda)
+                a2d = to_dev(torch, a2, cuda)
+                yS = torch.full((d.ndof,), -2.0, dtype=torch.float64, device=cuda)
+                yM = torch.full((d.ndof,), -2.0, dtype=torch.float64, device=cuda)
+                S, M = cd.StiffnessMatrix(fem), cd.MassMatrix(fem, a2d)
+                S.action(x[: d.ndof], yS)
+                M.action(x[: d.ndof], yM)
+                A = cd.HelmholtzOperator(omega, a2d, to_dev(torch, ax, cuda), fem, fs)
+                y = torch.empty(2 * d.ndof, dtype=torch.float64, device=cuda)
+                A.action(x, y)
+                assert A.fused()
+                # which instantiation ran
+                ug = int(kind == "structured" and affine == "1")  # uniform stiffness metric, read through scalar loads
+                ope = 64 if pe == "lane" else int(pe)
+                assert S.kernel() == f"op_patch_kernel<{nb},{nqS},0,NT={0 if ug else int(nt)},UG={ug},PEK={ope}> pe={ope}", S.kernel()
+                assert M.kernel() == f"op_patch_kernel<{nb},{nqM},1,NT={nt},UG=0,PEK={ope}> pe={ope}", M.kernel()  # a2 varies: never uniform
+                if pe == "lane" and nb <= 4 and (not ug or nb == 2):
+                    want = f"helm_lane_kernel<{nb},{nqS},{nqM},NT={nt},UG={ug}> pe=64"
+                else:
+                    # forced sizes apply to n_basis <= 4; affine plans are 64-element ones unless forced; a lane request that
+                    # does not apply (affine n_basis 3, 4; n_basis 5) leaves the default size
+                    hpe = (int(pe) if pe != "lane" else (64 if ug else 32)) if nb <= 4 else 32
+                    want = f"helm_patch_kernel<{nb},{nqS},{nqM},NT={nt},UG={ug},PEK={hpe}> pe={hpe}"
+                assert A.kernel() == want, (A.kernel(), want)
+                seen.add(A.kernel())
+                assert rel(yS.cpu().numpy(), refS) < 1e-12 and rel(yM.cpu().numpy(), refM) < 1e-12
+                assert rel(y.cpu().numpy(), refA) < 1e-12
+                # accumulate form: y <- y + c Op x
+                yS2 = to_dev(torch, refS, cuda).clone()
+                cd.StiffnessMatrix(fem).action(-1.0, x[: d.ndof], yS2)
+                assert float(yS2.abs().max()) < 1e-11 * float(np.abs(refS).max())
+                got[(pe, affine, nt)] = (yS.cpu().numpy(), yM.cpu().numpy(), y.cpu().numpy())
+    base = got[("32", "0", "0")]
     for key, val in got.items():
         for a, b in zip(val, base):
             assert rel(a, b) < 1e-13, key
+    if nb <= 4:  # the instantiations large general-geometry plans (the benchmark's) run
+        assert f"helm_lane_kernel<{nb},{nqS},{nqM},NT=1,UG=0> pe=64" in seen
+    if nb == 2 and kind == "structured":
+        assert "helm_lane_kernel<2,3,5,NT=1,UG=1> pe=64" in seen
 
 
 # ------------------------------------------------------------------ fused Helmholtz apply
@@ -564,6 +589,47 @@ def test_ddh_gmres_solve_fp64(cuda, kernel):
     assert out.success == info["success"]
     assert abs(out.num_matvec - info["num_matvec"]) <= 1
     assert rel(u.cpu().numpy(), u_ref) < 1e-8
+
+
+@pytest.mark.parametrize("nx", [16, 32])
+def test_ddh_fp32_solve_reference_flow(cuda, nx):
+    """The reference's own flow in the reference's own precision (examples/DDH.cpp:141-144: rhs -> float GMRES(20),
+    tol 1e-4 -> postprocess) on the benchmarked kernel (5: dense element matrix on the matrix cores), against the same flow
+    on the oracle in fp64 (and, at nx = 16, in fp32): same GMRES history to within a step, solutions to fp32 accuracy."""
+    import torch
+
+    import cuddhelmholtz_amd as cd
+
+    nb = 4
+    omega, d, h_a, fh = ddh_case(nx, nb)
+    fem = cd.H1Space(cd.Mesh2D.uniform_rect(nx, -1.0, 1.0, nx, -1.0, 1.0), cd.Basis(nb))
+    F = cd.DDH(omega, h_a, fem, nx, nx, precision="f32", kernel=5)
+    assert F.info()["kernel"] == 5
+    f = to_dev(torch, fh, cuda)
+    n = F.size()
+    b = torch.zeros(n, dtype=torch.float32, device=cuda)
+    lam = torch.zeros_like(b)
+    u = torch.zeros(2 * d.ndof, dtype=torch.float64, device=cuda)
+    F.rhs(f, b)
+    out = cd.gmres(n, lam, F, b, 20, 100, 1e-4)
+    F.postprocess(lam, f, u)
+    assert out.success
+    O64 = oracle.DDH(d, nx, nx, omega, h_a, np.float64)
+    lam64, info64 = oracle.gmres(O64.action, O64.rhs(fh), m=20, maxit=100, tol=1e-4)
+    u64 = O64.postprocess(lam64, fh)
+    assert info64["success"]
+    e = rel(u.cpu().numpy(), u64)
+    msg = f"DDH fp32 kernel 5 solve {nx}x{nx}: {out.num_matvec} matvecs (fp64 oracle {info64['num_matvec']}), u vs fp64 oracle {e:.2e}"
+    if nx == 16:
+        O32 = oracle.DDH(d, nx, nx, omega, h_a, np.float32)
+        lam32, info32 = oracle.gmres(O32.action, O32.rhs(fh), m=20, maxit=100, tol=1e-4, dtype=np.float32)
+        u32 = O32.postprocess(lam32, fh)
+        msg += f"; fp32 oracle: {info32['num_matvec']} matvecs, u vs fp64 oracle {rel(u32, u64):.2e}, GPU vs fp32 oracle {rel(u.cpu().numpy(), u32):.2e}"
+        assert abs(out.num_matvec - info32["num_matvec"]) <= 2
+    print(msg)
+    assert abs(out.num_matvec - info64["num_matvec"]) <= 2
+    # both runs stop at a relative residual of 1e-4, so the solutions agree to a small multiple of that
+    assert e < 2e-3
 
 
 def test_sharded_ddh_single_rank_equals_ddh(cuda):
