@@ -61,6 +61,8 @@ namespace cuddh
 
     struct StraightEdge : public Edge
     {
+        StraightEdge() : a{0.0, 0.0}, t{0.0, 0.0}, nrm{0.0, 0.0}, len(0.0) {} // slot of a mesh's edge store, assigned later
+
         /// segment x0 -> x1; `side` is the local side index in the first element (fixes the normal's sign)
         StraightEdge(const double *x0, const double *x1, int side)
         {
@@ -120,6 +122,8 @@ namespace cuddh
     class QuadElement : public Element
     {
     public:
+        QuadElement() : xc{{0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}} {} // slot of a mesh's element store, assigned later
+
         /// X has shape (2, 4): the corners in counter-clockwise order
         explicit QuadElement(const double *X)
         {

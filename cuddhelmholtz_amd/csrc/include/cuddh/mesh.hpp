@@ -5,7 +5,7 @@
 // first-seen order over (element, side); `uniform_rect` element id i + nx*j,
 // vertex id i + (nx+1)*j.  Edge lookup uses 64-bit keys, so meshes larger than
 // 214x214 elements are safe (the reference's 32-bit key overflows there,
-// source/Mesh2D.cpp:64-67).
+// source/Mesh2D.cpp:64-67).  `uniform_rect` builds the same mesh in closed form (no hashing, parallel over rows).
 #ifndef CUDDH_AMD_MESH_HPP
 #define CUDDH_AMD_MESH_HPP
 
@@ -99,15 +99,15 @@ namespace cuddh
             return _nodes[type == NodeType::BOUNDARY ? _boundary_nodes[i] : _interior_nodes[i]];
         }
 
-        const Edge *edge(int i) const { return _edges[i].get(); }
+        const Edge *edge(int i) const { return &_edges[i]; }
         const Edge *edge(int i, FaceType type) const
         {
-            return _edges[type == FaceType::BOUNDARY ? _boundary_edges[i] : _interior_edges[i]].get();
+            return &_edges[type == FaceType::BOUNDARY ? _boundary_edges[i] : _interior_edges[i]];
         }
 
         ivec boundary_edges() const;
 
-        const Element *element(int el) const { return _elements[el].get(); }
+        const Element *element(int el) const { return &_elements[el]; }
 
         const ElementMetricCollection &element_metrics(const QuadratureRule &quad) const;
         const EdgeMetricCollection &edge_metrics(const QuadratureRule &quad, FaceType edge_type) const;
@@ -117,9 +117,14 @@ namespace cuddh
         static Mesh2D uniform_rect(int nx, double ax, double bx, int ny, double ay, double by);
 
     private:
+        /// boundary / interior lists from the node and edge types, in id order
+        void classify();
+
+        // contiguous stores (the reference keeps one heap object per edge and element, include/Mesh2D.hpp:283-285;
+        // straight edges and bilinear quadrilaterals are the only kinds either code has)
         std::vector<Node> _nodes;
-        std::vector<std::unique_ptr<Edge>> _edges;
-        std::vector<std::unique_ptr<Element>> _elements;
+        std::vector<StraightEdge> _edges;
+        std::vector<QuadElement> _elements;
         std::vector<int> _interior_nodes, _boundary_nodes;
         std::vector<int> _boundary_edges, _interior_edges;
 

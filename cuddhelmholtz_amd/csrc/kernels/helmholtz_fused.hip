@@ -30,6 +30,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 #include "common.hpp"
@@ -70,6 +71,7 @@ struct cuddh_helmholtz_plan
     size_t bytes_alg = 0, bytes_actual = 0;
     int streaming = 0; // metric loads carry the non-temporal hint (plans larger than the infinity cache)
     int lane_form = 0; // fused apply through helm_lane_kernel (one element per lane, both components)
+    int prefetch = 0;  // lane form with the whole patch's metric block requested up front (one wavefront per SIMD)
     size_t bytes_affine = 0; // algorithmic bytes of the affine form (0 when neither metric array is uniform)
 };
 
@@ -483,8 +485,22 @@ namespace
     // x is consumed when the registers are filled and the same array then accumulates y (as in helm_mfma_kernel); the
     // boundary-face term re-reads its few x values from global memory.
     // UG: the stiffness metric is the same in every element and comes from the uniform table GU (scalar loads)
-    template <int NB, int NQS, int NQM, bool NT, bool UG>
-    __global__ void __launch_bounds__(64, (NB == 2 ? 5 : (NB == 3 ? 3 : 2))) helm_lane_kernel(HelmArgs A, const double *__restrict__ PS, const double *__restrict__ DS,
+    // PRE ("whole patch in the register file"): one wavefront per SIMD owns all 512 registers per lane (256 VGPR + 256 AGPR,
+    // loads can target either), so EVERY metric value of the patch -- 3 NQS^2 + NQM^2 doubles per lane, 139 for n_basis 4 = 278
+    // registers, 71 KB per wavefront -- is requested before the gather and the slices then run out of registers without a single
+    // further round trip.  The chain of a wavefront shrinks from 2 + NQS + NQM/2 dependent round trips to 3, and a CU keeps
+    // 4 x 63 loads x 512 B = 129 KB in flight instead of 8 x 7.7 KB.  Measured on the metric stream alone
+    // (profiles/tools/dma_stream.hip, profiles/r02/metric_stream_microbench.txt): slice-by-slice at 8 wavefronts per CU
+    // 4.4 TB/s, whole block up front at 4 wavefronts per CU 6.46 TB/s (a read-only stream on that box: 6.9); the same block
+    // through an LDS-DMA ring: 1.8-4.0 TB/s (one wavefront's LDS-DMA pieces are served one at a time, ~1.5 B/clk).
+    // In the real kernel it LOSES (1024^2: 434-442 us against 373-376 us for the chain; 357 us even with the slice arithmetic
+    // removed): with 4 x 32 KB per CU in flight (33 MB on the chip) every dependent round trip takes ~7 us, and a lone
+    // wavefront per SIMD has nothing to overlap its light round trips (dof indices -> x values -> destination slots) with:
+    // ~22 us per patch of exposed latency.  What limits these kernels is the NUMBER of dependent round trips a wavefront makes
+    // times the loaded latency (= bytes in flight / bandwidth), so every round trip must carry a full share of the bytes.
+    // Kept as a tested option (CUDDH_HELM_PRE=1); the default lane form is the chain with its light round trips merged.
+    template <int NB, int NQS, int NQM, bool NT, bool UG, bool PRE = false>
+    __global__ void __launch_bounds__(64, PRE ? 1 : (NB == 2 ? 5 : (NB == 3 ? 3 : 2))) helm_lane_kernel(HelmArgs A, const double *__restrict__ PS, const double *__restrict__ DS,
                                                               const double *__restrict__ PM, const double *__restrict__ PF,
                                                               const double *__restrict__ GU)
     {
@@ -518,23 +534,65 @@ namespace
                 for (int c = 0; c < 3; ++c)
                     g[3 * r + c] = UG ? GU[(q * 3 + c) * NQS + r] : metric_load<NT>(&Gp[((q * 3 + c) * NQS + r) * PEK]);
         };
-        double g_first[3 * NQS]; // first stiffness slice, requested before the gather
-        if constexpr (!UG)
+        // The chain form requests the first TWO stiffness slices before the gather: the element state (u, out: 8 NB^2 registers)
+        // is not live yet, so the registers are there, and the two light round trips of the gather (dof indices, then x
+        // values) each carry a slice instead of one of them carrying nothing.  The write-out's destination indices ride
+        // along too (below), so the wavefront makes two dependent round trips fewer than it used to.
+        // (n_basis 4 only: at n_basis 2 and 3 the launch bounds hold 5 and 3 wavefronts per SIMD and the extra live registers spill)
+        constexpr bool TWO_AHEAD = !UG && !PRE && NB >= 4;
+        constexpr bool EARLY_DEST = PRE || NB >= 4;
+        double g_first[3 * NQS], g_second[3 * NQS];
+        if constexpr (!UG && !PRE)
             load_stiff(0, g_first);
+        if constexpr (TWO_AHEAD)
+            load_stiff(1, g_second);
+        // PRE: the whole metric block of the patch, requested in this order: dof indices (above), stiffness metric, x values
+        // of the first gather pass, mass weights -- so that what the chain needs first is oldest (loads return in order)
+        double gS[PRE ? NQS : 1][3 * NQS];
+        double aW[PRE ? NQM : 1][NQM];
 
         constexpr int ROWS = 10; // 640 dofs per pass: an 8x8-element patch of n_basis 4 (625) in one
-        for (int base = 0; base < nloc; base += 64 * ROWS)
+        // where the write-out sends the first 64 ROWS results: requested with the other indices at kernel entry
+        const int *slot = A.slot_of + off;
+        int dest0[ROWS];
+        if constexpr (EARLY_DEST)
+#pragma unroll
+            for (int j = 0; j < ROWS; ++j)
+                dest0[j] = slot[min(64 * j + lane, nloc - 1)];
+        auto gather_pass = [&](int base, auto first)
         {
+            constexpr bool WITH_METRIC = PRE && decltype(first)::value;
             int gi[ROWS];
 #pragma unroll
             for (int j = 0; j < ROWS; ++j)
                 gi[j] = dofs[min(base + 64 * j + lane, nloc - 1)];
+            if constexpr (WITH_METRIC)
+            {
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (!UG)
+                {
+#pragma unroll
+                    for (int q = 0; q < NQS; ++q)
+                        load_stiff(q, gS[q]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
             double xu[ROWS], xv[ROWS];
 #pragma unroll
             for (int j = 0; j < ROWS; ++j)
             {
                 xu[j] = A.x[gi[j]];
                 xv[j] = A.x[A.ndof + gi[j]];
+            }
+            if constexpr (WITH_METRIC)
+            {
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < NQM; ++q)
+#pragma unroll
+                    for (int r = 0; r < NQM; ++r)
+                        aW[q][r] = metric_load<NT>(&ap[(q * NQM + r) * PEK]);
+                __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
             for (int j = 0; j < ROWS; ++j)
@@ -546,7 +604,10 @@ namespace
                     xy[ML + i] = xv[j];
                 }
             }
-        }
+        };
+        gather_pass(0, std::true_type{});
+        for (int base = 64 * ROWS; base < nloc; base += 64 * ROWS)
+            gather_pass(base, std::false_type{});
         __syncthreads();
 
         auto lix_of = [&](int n) -> int { return (n & 1) ? static_cast<int>(lpk[n >> 1] >> 16) : static_cast<int>(lpk[n >> 1] & 0xFFFFu); };
@@ -654,10 +715,32 @@ namespace
             }
         };
 
-        if constexpr (!UG)
+        if constexpr (PRE)
+        {
+            // every metric value is already on its way (or here): the slices run straight through, fully unrolled so that the
+            // arrays stay in registers
+#pragma unroll
+            for (int q = 0; q < NQS; ++q)
+            {
+                if constexpr (UG)
+                {
+                    double g[3 * NQS];
+                    load_stiff(q, g);
+                    stiff_slice(q, g);
+                }
+                else
+                    stiff_slice(q, gS[q]);
+            }
+#pragma unroll
+            for (int q = 0; q < NQM; ++q)
+                mass_slice(q, aW[q]);
+        }
+        if constexpr (!UG && !PRE)
             stiff_slice(0, g_first);
+        if constexpr (TWO_AHEAD)
+            stiff_slice(1, g_second);
 #pragma unroll 1
-        for (int q = UG ? 0 : 1; q < NQS; ++q)
+        for (int q = PRE ? NQS : (UG ? 0 : (TWO_AHEAD ? 2 : 1)); q < NQS; ++q)
         {
             double g[3 * NQS];
             load_stiff(q, g);
@@ -666,7 +749,7 @@ namespace
         // two mass slices per round trip: 2 x NQM values are no more registers than the 3 x NQS of a stiffness slice, which
         // are dead by now, and the chain of dependent round trips shrinks from NQS + NQM to NQS + NQM / 2
 #pragma unroll 1
-        for (int q = 0; q + 1 < NQM; q += 2)
+        for (int q = PRE ? NQM : 0; q + 1 < NQM; q += 2)
         {
             double am0[NQM], am1[NQM];
 #pragma unroll
@@ -678,7 +761,7 @@ namespace
             mass_slice(q, am0);
             mass_slice(q + 1, am1);
         }
-        if constexpr (NQM % 2 == 1)
+        if constexpr (NQM % 2 == 1 && !PRE)
         {
             double am[NQM];
 #pragma unroll
@@ -687,11 +770,10 @@ namespace
             mass_slice(NQM - 1, am);
         }
 
-        const int *slot = A.slot_of + off;
-        int dest0[ROWS];
+        if constexpr (!EARLY_DEST)
 #pragma unroll
-        for (int j = 0; j < ROWS; ++j)
-            dest0[j] = slot[min(64 * j + lane, nloc - 1)];
+            for (int j = 0; j < ROWS; ++j)
+                dest0[j] = slot[min(64 * j + lane, nloc - 1)];
 
         // accumulate in colour phases; the v row is negated (symmetrised system)
         for (int c = 0; c < A.ncol; ++c)
@@ -959,6 +1041,19 @@ namespace
             {
                 const size_t lds = (size_t)2 * p->max_loc * sizeof(double);
                 const dim3 grid(8 * A.xcd_chunk), block(64);
+                if (p->prefetch)
+                {
+                    // whole-patch prefetch: one wavefront per SIMD, the patch's metric block requested up front
+                    if (p->Gu && p->streaming)
+                        hipLaunchKernelGGL((helm_lane_kernel<NB, NQS, NQM, true, true, true>), grid, block, lds, st, A, p->PS, p->DS, p->PM, p->PF, p->Gu);
+                    else if (p->Gu)
+                        hipLaunchKernelGGL((helm_lane_kernel<NB, NQS, NQM, false, true, true>), grid, block, lds, st, A, p->PS, p->DS, p->PM, p->PF, p->Gu);
+                    else if (p->streaming)
+                        hipLaunchKernelGGL((helm_lane_kernel<NB, NQS, NQM, true, false, true>), grid, block, lds, st, A, p->PS, p->DS, p->PM, p->PF, p->Gu);
+                    else
+                        hipLaunchKernelGGL((helm_lane_kernel<NB, NQS, NQM, false, false, true>), grid, block, lds, st, A, p->PS, p->DS, p->PM, p->PF, p->Gu);
+                    return;
+                }
                 if (p->Gu && p->streaming)
                     hipLaunchKernelGGL((helm_lane_kernel<NB, NQS, NQM, true, true>), grid, block, lds, st, A, p->PS, p->DS, p->PM, p->PF, p->Gu);
                 else if (p->Gu)
@@ -2284,7 +2379,16 @@ extern "C"
         const int err = build_plan(out, ndof, n_elem, nb, h_I, h_xy, nqS, h_PS, h_DS, G_S, nqM, h_PM, a_M, n_faces, h_fI, h_face_elem, nqF,
                                    h_PF, a_F, pe);
         if (!err && *out)
+        {
             (*out)->lane_form = lane_form && (!(*out)->Gu || affine_lane);
+            // the lane form with the whole metric block in the register file (PRE, one wavefront per SIMD): measured SLOWER
+            // than the slice-by-slice chain at two wavefronts per SIMD (1024^2, n_basis 4: 434-442 vs 373-376 us), although
+            // the metric stream alone runs at 6.46 TB/s that way -- see the comment at the kernel.  CUDDH_HELM_PRE=1 selects it
+            // for A/B runs; tests keep it correct.
+            (*out)->prefetch = 0;
+            if (const char *e = std::getenv("CUDDH_HELM_PRE"))
+                (*out)->prefetch = (*out)->lane_form && std::atoi(e) != 0;
+        }
         return err;
     }
 
@@ -2413,7 +2517,7 @@ extern "C"
         if (fused && p->Gm && p->Am)
             std::snprintf(buf, cap, "helm_mfma_kernel<%d,%d,%d> pe=16 affine=%d", p->nb, p->nqS, p->nqM, p->gm_stride == 0 ? 1 : 0);
         else if (fused && p->nb <= 4 && p->pe == 64 && p->lane_form)
-            std::snprintf(buf, cap, "helm_lane_kernel<%d,%d,%d,NT=%d,UG=%d> pe=64", p->nb, p->nqS, p->nqM, nt, p->Gu ? 1 : 0);
+            std::snprintf(buf, cap, "helm_lane_kernel<%d,%d,%d,NT=%d,UG=%d%s> pe=64", p->nb, p->nqS, p->nqM, nt, p->Gu ? 1 : 0, p->prefetch ? ",PRE=1" : "");
         else if (fused)
             std::snprintf(buf, cap, "helm_patch_kernel<%d,%d,%d,NT=%d,UG=%d,PEK=%d> pe=%d", p->nb, p->nqS, p->nqM, nt, p->Gu ? 1 : 0, p->pe, p->pe);
         else if (p->Gm || p->Am)

@@ -4,6 +4,7 @@
 #include "cuddh/ddh.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -11,6 +12,7 @@
 #include <type_traits>
 #include <vector>
 
+#include "cuddh/parallel.hpp"
 #include "cuddh_hip.h"
 
 namespace cuddh
@@ -67,9 +69,12 @@ namespace cuddh
             const int ndx = nx / nel1d, ndy = ny / nel1d;
             n_domains = ndx * ndy;
             std::vector<int> labels(static_cast<std::size_t>(nx) * ny);
-            for (int j = 0; j < ny; ++j)
-                for (int i = 0; i < nx; ++i)
-                    labels[i + static_cast<std::size_t>(nx) * j] = (i / nel1d) + ndx * (j / nel1d);
+            parallel_for(static_cast<std::size_t>(ny), [&](std::size_t j0, std::size_t j1, int)
+            {
+                for (int j = static_cast<int>(j0); j < static_cast<int>(j1); ++j)
+                    for (int i = 0; i < nx; ++i)
+                        labels[i + static_cast<std::size_t>(nx) * j] = (i / nel1d) + ndx * (j / nel1d);
+            }, 8);
 
             efem.reset(new EnsembleSpace(fem, n_domains, labels.data()));
             timer.lap("EnsembleSpace");
@@ -144,30 +149,33 @@ namespace cuddh
             _sI.resize(nb * nb * mx_elem_per_dom * n_domains);
             auto sI = reshape(_sI.host_write(), nb, nb, mx_elem_per_dom, n_domains);
 
-            std::vector<int> new_of_old(mx_dof);
-            for (int s = 0; s < n_domains; ++s)
+            parallel_for(static_cast<std::size_t>(n_domains), [&](std::size_t s0, std::size_t s1, int)
             {
-                const int nd = sizes(s), nf = fsizes(s);
-                std::fill(new_of_old.begin(), new_of_old.end(), -1);
-                int next = 0;
-                for (; next < nf; ++next)
+                std::vector<int> new_of_old(mx_dof);
+                for (int s = static_cast<int>(s0); s < static_cast<int>(s1); ++s)
                 {
-                    const int old = faceproj(next, s);
-                    new_of_old[old] = next;
-                    gI(next, s) = g_inds(old, s);
-                }
-                for (int old = 0; old < nd; ++old)
-                    if (new_of_old[old] < 0)
+                    const int nd = sizes(s), nf = fsizes(s);
+                    std::fill(new_of_old.begin(), new_of_old.end(), -1);
+                    int next = 0;
+                    for (; next < nf; ++next)
                     {
+                        const int old = faceproj(next, s);
                         new_of_old[old] = next;
                         gI(next, s) = g_inds(old, s);
-                        ++next;
                     }
-                for (int el = 0; el < s_nel(s); ++el)
-                    for (int l = 0; l < nb; ++l)
-                        for (int k = 0; k < nb; ++k)
-                            sI(k, l, el, s) = new_of_old[s_inds(k, l, el, s)];
-            }
+                    for (int old = 0; old < nd; ++old)
+                        if (new_of_old[old] < 0)
+                        {
+                            new_of_old[old] = next;
+                            gI(next, s) = g_inds(old, s);
+                            ++next;
+                        }
+                    for (int el = 0; el < s_nel(s); ++el)
+                        for (int l = 0; l < nb; ++l)
+                            for (int k = 0; k < nb; ++k)
+                                sI(k, l, el, s) = new_of_old[s_inds(k, l, el, s)];
+                }
+            }, 16);
 
             timer.lap("face-first renumbering");
             // ---- local operators
@@ -188,14 +196,64 @@ namespace cuddh
             auto fem_gi = fem.global_indices(MemorySpace::HOST);
 
             timer.lap("element metrics");
-            // global lumped mass and its inverse
+            // global lumped mass and its inverse.  The reference adds the element contributions of a dof in element order
+            // (source/DDH.cpp:559-566); to keep that order (and with it every bit of the sum) with several threads, a dof
+            // touched by ONE range of elements is summed by that range, the few touched by several ranges afterwards, serially.
             std::vector<double> inv_mass(g_ndof, 0.0);
-            for (int el = 0; el < g_elem; ++el)
-                for (int j = 0; j < nb; ++j)
-                    for (int i = 0; i < nb; ++i)
-                        inv_mass[fem_gi(i, j, el)] += q.w(i) * q.w(j) * detJ(i, j, el);
-            for (auto &v : inv_mass)
-                v = 1.0 / v;
+            {
+                const int nn = nb * nb;
+                std::vector<std::atomic<int>> toucher(g_ndof); // -1 none, c one range, -2 several
+                parallel_for(static_cast<std::size_t>(g_ndof), [&](std::size_t g0, std::size_t g1, int)
+                {
+                    for (std::size_t g = g0; g < g1; ++g)
+                        toucher[g].store(-1, std::memory_order_relaxed);
+                });
+                parallel_for(static_cast<std::size_t>(g_elem), [&](std::size_t e0, std::size_t e1, int c)
+                {
+                    for (std::size_t v = e0 * nn; v < e1 * nn; ++v)
+                    {
+                        std::atomic<int> &t = toucher[fem_gi[v]];
+                        int cur = t.load(std::memory_order_relaxed);
+                        while (cur != c && cur != -2 && !t.compare_exchange_weak(cur, cur == -1 ? c : -2, std::memory_order_relaxed))
+                        {
+                        }
+                    }
+                }, 64);
+                const int C = chunk_count(static_cast<std::size_t>(g_elem), 64);
+                std::vector<std::vector<int>> seam(C); // elements with a dof that several ranges touch, per range, in order
+                parallel_for(static_cast<std::size_t>(g_elem), [&](std::size_t e0, std::size_t e1, int c)
+                {
+                    for (int el = static_cast<int>(e0); el < static_cast<int>(e1); ++el)
+                    {
+                        bool on_seam = false;
+                        for (int j = 0; j < nb; ++j)
+                            for (int i = 0; i < nb; ++i)
+                            {
+                                const int g = fem_gi(i, j, el);
+                                if (toucher[g].load(std::memory_order_relaxed) == -2)
+                                    on_seam = true;
+                                else
+                                    inv_mass[g] += q.w(i) * q.w(j) * detJ(i, j, el);
+                            }
+                        if (on_seam)
+                            seam[c].push_back(el);
+                    }
+                }, 64);
+                for (int c = 0; c < C; ++c)
+                    for (const int el : seam[c])
+                        for (int j = 0; j < nb; ++j)
+                            for (int i = 0; i < nb; ++i)
+                            {
+                                const int g = fem_gi(i, j, el);
+                                if (toucher[g].load(std::memory_order_relaxed) == -2)
+                                    inv_mass[g] += q.w(i) * q.w(j) * detJ(i, j, el);
+                            }
+                parallel_for(static_cast<std::size_t>(g_ndof), [&](std::size_t g0, std::size_t g1, int)
+                {
+                    for (std::size_t g = g0; g < g1; ++g)
+                        inv_mass[g] = 1.0 / inv_mass[g];
+                });
+            }
 
             _m.resize(mx_dof * n_domains);
             _H.resize(mx_fdof * n_domains);
@@ -210,34 +268,37 @@ namespace cuddh
             auto n_faces = efem->n_faces(MemorySpace::HOST);
             auto f_inds = efem->face_indices(MemorySpace::HOST);
 
-            for (int s = 0; s < n_domains; ++s)
+            parallel_for(static_cast<std::size_t>(n_domains), [&](std::size_t s0, std::size_t s1, int)
             {
-                // the storage type accumulates, as in the reference (float += double)
-                for (int el = 0; el < s_nel(s); ++el)
+                for (int s = static_cast<int>(s0); s < static_cast<int>(s1); ++s)
                 {
-                    const int g_el = s_elems(el, s);
-                    for (int j = 0; j < nb; ++j)
+                    // the storage type accumulates, as in the reference (float += double)
+                    for (int el = 0; el < s_nel(s); ++el)
+                    {
+                        const int g_el = s_elems(el, s);
+                        for (int j = 0; j < nb; ++j)
+                            for (int i = 0; i < nb; ++i)
+                            {
+                                Real &acc = m(sI(i, j, el, s), s);
+                                acc = static_cast<Real>(acc + q.w(i) * q.w(j) * detJ(i, j, g_el));
+                            }
+                    }
+                    for (int i = 0; i < sizes(s); ++i)
+                    {
+                        A(i, s) = static_cast<Real>(h_a[gI(i, s)]);
+                        gmi(i, s) = static_cast<Real>(inv_mass[gI(i, s)]);
+                    }
+                    for (int f = 0; f < n_faces(s); ++f)
+                    {
+                        const Edge *edge = fem.mesh().edge(faces(f, s));
                         for (int i = 0; i < nb; ++i)
                         {
-                            Real &acc = m(sI(i, j, el, s), s);
-                            acc = static_cast<Real>(acc + q.w(i) * q.w(j) * detJ(i, j, g_el));
+                            Real &acc = H(f_inds(i, f, s), s);
+                            acc = static_cast<Real>(acc + edge->measure(q.x(i)) * q.w(i));
                         }
-                }
-                for (int i = 0; i < sizes(s); ++i)
-                {
-                    A(i, s) = static_cast<Real>(h_a[gI(i, s)]);
-                    gmi(i, s) = static_cast<Real>(inv_mass[gI(i, s)]);
-                }
-                for (int f = 0; f < n_faces(s); ++f)
-                {
-                    const Edge *edge = fem.mesh().edge(faces(f, s));
-                    for (int i = 0; i < nb; ++i)
-                    {
-                        Real &acc = H(f_inds(i, f, s), s);
-                        acc = static_cast<Real>(acc + edge->measure(q.x(i)) * q.w(i));
                     }
                 }
-            }
+            }, 16);
 
             timer.lap("lumped masses, H, a");
             requested_kernel = kernel;

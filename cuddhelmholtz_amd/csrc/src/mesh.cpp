@@ -1,6 +1,9 @@
 // Mesh construction and metric caches.
 #include "cuddh/mesh.hpp"
 
+#include "cuddh/error.hpp"
+#include "cuddh/parallel.hpp"
+
 #include <algorithm>
 #include <cstdint>
 #include <limits>
@@ -46,11 +49,11 @@ namespace cuddh
                 X[2 * i + 1] = x_[2 * c[i] + 1];
                 mesh._nodes[c[i]].connected_elements.push_back({i, el});
             }
-            auto q = std::make_unique<QuadElement>(X);
-            q->id = el;
+            QuadElement q(X);
+            q.id = el;
             for (int i = 0; i < 4; ++i)
-                q->nodes[i] = c[i];
-            mesh._elements[el] = std::move(q);
+                q.nodes[i] = c[i];
+            mesh._elements[el] = q;
         }
 
         // edges, numbered in the order (element, side) first reaches them
@@ -67,74 +70,150 @@ namespace cuddh
                 if (it == seen.end())
                 {
                     const int id = static_cast<int>(mesh._edges.size());
-                    auto e = std::make_unique<StraightEdge>(x_ + 2 * v0, x_ + 2 * v1, s);
-                    e->id = id;
-                    e->type = FaceType::BOUNDARY;
-                    e->nodes[0] = v0;
-                    e->nodes[1] = v1;
-                    e->elements[0] = el;
-                    e->sides[0] = s;
-                    e->delta = 1;
-                    mesh._edges.push_back(std::move(e));
+                    StraightEdge e(x_ + 2 * v0, x_ + 2 * v1, s);
+                    e.id = id;
+                    e.type = FaceType::BOUNDARY;
+                    e.nodes[0] = v0;
+                    e.nodes[1] = v1;
+                    e.elements[0] = el;
+                    e.sides[0] = s;
+                    e.delta = 1;
+                    mesh._edges.push_back(e);
                     seen.emplace(key, id);
                 }
                 else
                 {
-                    Edge *e = mesh._edges[it->second].get();
-                    e->type = FaceType::INTERIOR;
-                    e->elements[1] = el;
-                    e->sides[1] = s;
+                    Edge &e = mesh._edges[it->second];
+                    e.type = FaceType::INTERIOR;
+                    e.elements[1] = el;
+                    e.sides[1] = s;
                     // same direction iff this element's start vertex is the first element's start vertex
-                    e->delta = (v0 == e->nodes[0]) ? 1 : -1;
+                    e.delta = (v0 == e.nodes[0]) ? 1 : -1;
                     mesh._nodes[v0].type = NodeType::INTERIOR;
                     mesh._nodes[v1].type = NodeType::INTERIOR;
                 }
             }
         }
-
-        for (const auto &e : mesh._edges)
-            (e->type == FaceType::BOUNDARY ? mesh._boundary_edges : mesh._interior_edges).push_back(e->id);
-        for (const auto &nd : mesh._nodes)
-            (nd.type == NodeType::BOUNDARY ? mesh._boundary_nodes : mesh._interior_nodes).push_back(nd.id);
-
+        mesh.classify();
         return mesh;
     }
 
+    void Mesh2D::classify()
+    {
+        for (const auto &e : _edges)
+            (e.type == FaceType::BOUNDARY ? _boundary_edges : _interior_edges).push_back(e.id);
+        for (const auto &nd : _nodes)
+            (nd.type == NodeType::BOUNDARY ? _boundary_nodes : _interior_nodes).push_back(nd.id);
+    }
+
+    // The mesh from_vertices() builds for the lattice of (nx+1) x (ny+1) vertices (vertex id i + (nx+1) j, element id
+    // i + nx j, corners sw, se, ne, nw; reference source/Mesh2D.cpp:138-171), written down in closed form: what the
+    // edge hash of from_vertices discovers is known in advance on a lattice, so rows are filled in parallel.
+    //   * edge ids in first-seen order over (element, side 0..3): element (i, j) is the first to see its bottom edge iff
+    //     j == 0, its right and top edges always, its left edge iff i == 0;
+    //   * the right edge of (i, j) is side 3 of (i+1, j), the top edge side 0 of (i, j+1), both traversed in the same
+    //     direction (delta = +1: uniform_rect never produces a reversed edge);
+    //   * a vertex is INTERIOR iff an interior edge ends in it, i.e. unless it is one of the four corners of the lattice
+    //     (or, on a one-element-wide lattice, lies on a side no interior edge reaches);
+    //   * a vertex lists the elements around it in increasing element id: sw (as its corner 2), se (3), nw (1), ne (0).
+    // tests/test_host_numbering.py compares the result with the oracle's restatement of from_vertices.
     Mesh2D Mesh2D::uniform_rect(int nx, double ax, double bx, int ny, double ay, double by)
     {
+        if (nx < 1 || ny < 1)
+            cuddh_error("Mesh2D::uniform_rect error: nx and ny must be positive.");
         const int npx = nx + 1, npy = ny + 1;
-        std::vector<double> coo(static_cast<std::size_t>(2) * npx * npy);
-        std::vector<int> quads(static_cast<std::size_t>(4) * nx * ny);
-
         const double dx = (bx - ax) / nx, dy = (by - ay) / ny;
-        for (int j = 0; j < npy; ++j)
+        auto vx = [&](int i) { return ax + dx * i; };
+        auto vy = [&](int j) { return ay + dy * j; };
+
+        Mesh2D mesh;
+        mesh._nodes.resize(static_cast<std::size_t>(npx) * npy);
+        mesh._elements.resize(static_cast<std::size_t>(nx) * ny);
+        const std::size_t row0 = static_cast<std::size_t>(3) * nx + 1, rowk = static_cast<std::size_t>(2) * nx + 1;
+        mesh._edges.resize(row0 + rowk * (ny - 1));
+
+        detail::parallel_for(static_cast<std::size_t>(npy), [&](std::size_t j0, std::size_t j1, int)
         {
-            const double y = ay + dy * j;
-            for (int i = 0; i < npx; ++i)
+            for (int j = static_cast<int>(j0); j < static_cast<int>(j1); ++j)
+                for (int i = 0; i < npx; ++i)
+                {
+                    Node &nd = mesh._nodes[static_cast<std::size_t>(i) + static_cast<std::size_t>(npx) * j];
+                    nd.id = i + npx * j;
+                    nd.x[0] = vx(i);
+                    nd.x[1] = vy(j);
+                    const bool vertical_interior = i > 0 && i < nx;   // an interior vertical edge ends here
+                    const bool horizontal_interior = j > 0 && j < ny; // an interior horizontal edge ends here
+                    nd.type = (vertical_interior || horizontal_interior) ? NodeType::INTERIOR : NodeType::BOUNDARY;
+                    nd.connected_elements.reserve(4);
+                    if (i > 0 && j > 0)
+                        nd.connected_elements.push_back({2, (i - 1) + nx * (j - 1)});
+                    if (i < nx && j > 0)
+                        nd.connected_elements.push_back({3, i + nx * (j - 1)});
+                    if (i > 0 && j < ny)
+                        nd.connected_elements.push_back({1, (i - 1) + nx * j});
+                    if (i < nx && j < ny)
+                        nd.connected_elements.push_back({0, i + nx * j});
+                }
+        }, 8);
+
+        detail::parallel_for(static_cast<std::size_t>(ny), [&](std::size_t j0, std::size_t j1, int)
+        {
+            for (int j = static_cast<int>(j0); j < static_cast<int>(j1); ++j)
             {
-                const std::size_t v = static_cast<std::size_t>(i) + static_cast<std::size_t>(npx) * j;
-                coo[2 * v] = ax + dx * i;
-                coo[2 * v + 1] = y;
+                // first edge id of row j, then 3 (row 0) or 2 new edges per element, plus the left edge of element 0
+                const std::size_t base = j == 0 ? 0 : row0 + rowk * (j - 1);
+                const int per = j == 0 ? 3 : 2;
+                for (int i = 0; i < nx; ++i)
+                {
+                    const int el = i + nx * j;
+                    const int sw = i + npx * j, se = sw + 1, ne = sw + 1 + npx, nw = sw + npx;
+                    const double X[8] = {vx(i), vy(j), vx(i + 1), vy(j), vx(i + 1), vy(j + 1), vx(i), vy(j + 1)};
+                    QuadElement q(X);
+                    q.id = el;
+                    q.nodes[0] = sw;
+                    q.nodes[1] = se;
+                    q.nodes[2] = ne;
+                    q.nodes[3] = nw;
+                    mesh._elements[el] = q;
+
+                    std::size_t id = base + static_cast<std::size_t>(per) * i + (i > 0 ? 1 : 0);
+                    auto put = [&](int side, int v0, int v1, const double *x0, const double *x1, int el1, int side1)
+                    {
+                        StraightEdge e(x0, x1, side);
+                        e.id = static_cast<int>(id);
+                        e.nodes[0] = v0;
+                        e.nodes[1] = v1;
+                        e.elements[0] = el;
+                        e.sides[0] = side;
+                        e.delta = 1;
+                        if (el1 >= 0)
+                        {
+                            e.type = FaceType::INTERIOR;
+                            e.elements[1] = el1;
+                            e.sides[1] = side1;
+                        }
+                        else
+                            e.type = FaceType::BOUNDARY;
+                        mesh._edges[id++] = e;
+                    };
+                    if (j == 0)
+                        put(0, sw, se, X + 0, X + 2, -1, -1);                                  // bottom: c0 -> c1
+                    put(1, se, ne, X + 2, X + 4, i + 1 < nx ? el + 1 : -1, 3);                 // right:  c1 -> c2
+                    put(2, nw, ne, X + 6, X + 4, j + 1 < ny ? el + nx : -1, 0);                // top:    c3 -> c2
+                    if (i == 0)
+                        put(3, sw, nw, X + 0, X + 6, -1, -1);                                  // left:   c0 -> c3
+                }
             }
-        }
-        for (int j = 0; j < ny; ++j)
-            for (int i = 0; i < nx; ++i)
-            {
-                int *c = quads.data() + 4 * (static_cast<std::size_t>(i) + static_cast<std::size_t>(nx) * j);
-                const int sw = i + npx * j;
-                c[0] = sw;
-                c[1] = sw + 1;
-                c[2] = sw + 1 + npx;
-                c[3] = sw + npx;
-            }
-        return from_vertices(npx * npy, coo.data(), nx * ny, quads.data());
+        }, 8);
+        mesh.classify();
+        return mesh;
     }
 
     double Mesh2D::min_h() const
     {
         double h = std::numeric_limits<double>::infinity();
         for (const auto &e : _edges)
-            h = std::min(h, e->length());
+            h = std::min(h, e.length());
         return h;
     }
 
@@ -142,7 +221,7 @@ namespace cuddh
     {
         double h = -1.0;
         for (const auto &e : _edges)
-            h = std::max(h, e->length());
+            h = std::max(h, e.length());
         return h;
     }
 
@@ -179,17 +258,20 @@ namespace cuddh
             const int m = quad.size(), nel = mesh.n_elem();
             out.resize(dim * m * m * nel);
             double *dst = out.host_write();
-            for (int el = 0; el < nel; ++el)
+            detail::parallel_for(static_cast<std::size_t>(nel), [&](std::size_t e0, std::size_t e1, int)
             {
-                const Element *e = mesh.element(el);
-                double *d = dst + static_cast<std::size_t>(dim) * m * m * el;
-                for (int j = 0; j < m; ++j)
-                    for (int i = 0; i < m; ++i)
-                    {
-                        const double xi[2] = {quad.x(i), quad.x(j)};
-                        eval(d + dim * (i + m * j), e, xi);
-                    }
-            }
+                for (int el = static_cast<int>(e0); el < static_cast<int>(e1); ++el)
+                {
+                    const Element *e = mesh.element(el);
+                    double *d = dst + static_cast<std::size_t>(dim) * m * m * el;
+                    for (int j = 0; j < m; ++j)
+                        for (int i = 0; i < m; ++i)
+                        {
+                            const double xi[2] = {quad.x(i), quad.x(j)};
+                            eval(d + dim * (i + m * j), e, xi);
+                        }
+                }
+            });
         }
     } // namespace
 

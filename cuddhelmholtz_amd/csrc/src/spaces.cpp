@@ -1,8 +1,10 @@
 // Global numbering of the H1 space and of face spaces.
 #include "cuddh/spaces.hpp"
 
+#include <atomic>
 #include <vector>
 
+#include "cuddh/parallel.hpp"
 #include "cuddh_hip.h"
 
 namespace cuddh
@@ -40,58 +42,109 @@ namespace cuddh
         const int N = nb * nb * n_elem;
         int *I = _I.host_write();
 
-        // owner[v] = flat index of the node v is a copy of (-1: v owns itself)
+        // owner[v] = flat index of the node v is a copy of (-1: v owns itself).  The loops below are the reference's
+        // (source/H1Space.cpp:47-106) cut into contiguous ranges for the set-up threads; every entry has one writer.
         std::vector<int> owner(N, -1);
 
         if (nb > 2)
         {
             const int n_int = _mesh.n_edges(FaceType::INTERIOR);
-            for (int e = 0; e < n_int; ++e)
+            detail::parallel_for(static_cast<std::size_t>(n_int), [&](std::size_t e0, std::size_t e1, int)
             {
-                const Edge *edge = _mesh.edge(e, FaceType::INTERIOR);
-                const bool flip = edge->delta < 0;
-                for (int i = 1; i < nb - 1; ++i)
+                for (int e = static_cast<int>(e0); e < static_cast<int>(e1); ++e)
                 {
-                    const int mine = side_node(nb, i, edge->sides[0], edge->elements[0]);
-                    const int theirs = side_node(nb, flip ? nb - 1 - i : i, edge->sides[1], edge->elements[1]);
-                    owner[theirs] = mine;
+                    const Edge *edge = _mesh.edge(e, FaceType::INTERIOR);
+                    const bool flip = edge->delta < 0;
+                    for (int i = 1; i < nb - 1; ++i)
+                    {
+                        const int mine = side_node(nb, i, edge->sides[0], edge->elements[0]);
+                        const int theirs = side_node(nb, flip ? nb - 1 - i : i, edge->sides[1], edge->elements[1]);
+                        owner[theirs] = mine;
+                    }
                 }
-            }
+            });
         }
 
         const int n_nodes = _mesh.n_nodes();
-        for (int k = 0; k < n_nodes; ++k)
+        detail::parallel_for(static_cast<std::size_t>(n_nodes), [&](std::size_t k0, std::size_t k1, int)
         {
-            const auto &adj = _mesh.node(k).connected_elements;
-            if (adj.empty())
-                continue;
-            const int first = corner_node(nb, adj[0].i, adj[0].id);
-            for (std::size_t t = 1; t < adj.size(); ++t)
-                owner[corner_node(nb, adj[t].i, adj[t].id)] = first;
-        }
+            for (int k = static_cast<int>(k0); k < static_cast<int>(k1); ++k)
+            {
+                const auto &adj = _mesh.node(k).connected_elements;
+                if (adj.empty())
+                    continue;
+                const int first = corner_node(nb, adj[0].i, adj[0].id);
+                for (std::size_t t = 1; t < adj.size(); ++t)
+                    owner[corner_node(nb, adj[t].i, adj[t].id)] = first;
+            }
+        });
 
-        int next = 0;
-        for (int v = 0; v < N; ++v)
-            if (owner[v] < 0)
-                I[v] = next++;
-        for (int v = 0; v < N; ++v)
-            if (owner[v] >= 0)
-                I[v] = I[owner[v]];
-        ndof = next;
+        // owners are numbered in increasing flat index: count per range, prefix sum, assign; then the copies
+        const int C = detail::chunk_count(static_cast<std::size_t>(N));
+        std::vector<int> first_id(C + 1, 0);
+        detail::parallel_for(static_cast<std::size_t>(N), [&](std::size_t v0, std::size_t v1, int c)
+        {
+            int cnt = 0;
+            for (std::size_t v = v0; v < v1; ++v)
+                cnt += owner[v] < 0;
+            first_id[c + 1] = cnt;
+        });
+        for (int c = 0; c < C; ++c)
+            first_id[c + 1] += first_id[c];
+        ndof = first_id[C];
+        detail::parallel_for(static_cast<std::size_t>(N), [&](std::size_t v0, std::size_t v1, int c)
+        {
+            int next = first_id[c];
+            for (std::size_t v = v0; v < v1; ++v)
+                if (owner[v] < 0)
+                    I[v] = next++;
+        });
+        detail::parallel_for(static_cast<std::size_t>(N), [&](std::size_t v0, std::size_t v1, int)
+        {
+            for (std::size_t v = v0; v < v1; ++v)
+                if (owner[v] >= 0)
+                    I[v] = I[owner[v]];
+        });
 
+        // collocation points: the reference overwrites a shared dof's point element after element, the highest element wins
+        // (source/H1Space.cpp:108-126).  In parallel: each range of elements first stamps the dofs it touches with its range
+        // number (highest wins), then writes only the dofs it won, in element order -- the same winner as the serial loop.
         _xy.resize(2 * ndof);
         double *xy = _xy.host_write();
         const QuadratureRule &gll = _basis.quadrature();
-        for (int el = 0; el < n_elem; ++el)
+        std::vector<std::atomic<int>> winner(ndof);
+        detail::parallel_for(static_cast<std::size_t>(ndof), [&](std::size_t g0, std::size_t g1, int)
         {
-            const Element *elem = _mesh.element(el);
-            for (int j = 0; j < nb; ++j)
-                for (int i = 0; i < nb; ++i)
+            for (std::size_t g = g0; g < g1; ++g)
+                winner[g].store(-1, std::memory_order_relaxed);
+        });
+        detail::parallel_for(static_cast<std::size_t>(n_elem), [&](std::size_t e0, std::size_t e1, int c)
+        {
+            for (std::size_t v = e0 * nb * nb; v < e1 * nb * nb; ++v)
+            {
+                std::atomic<int> &w = winner[I[v]];
+                int cur = w.load(std::memory_order_relaxed);
+                while (cur < c && !w.compare_exchange_weak(cur, c, std::memory_order_relaxed))
                 {
-                    const double xi[2] = {gll.x(i), gll.x(j)};
-                    elem->physical_coordinates(xi, xy + 2 * I[i + nb * (j + nb * el)]);
                 }
-        }
+            }
+        }, 64);
+        detail::parallel_for(static_cast<std::size_t>(n_elem), [&](std::size_t e0, std::size_t e1, int c)
+        {
+            for (int el = static_cast<int>(e0); el < static_cast<int>(e1); ++el)
+            {
+                const Element *elem = _mesh.element(el);
+                for (int j = 0; j < nb; ++j)
+                    for (int i = 0; i < nb; ++i)
+                    {
+                        const int g = I[i + nb * (j + nb * el)];
+                        if (winner[g].load(std::memory_order_relaxed) != c)
+                            continue;
+                        const double xi[2] = {gll.x(i), gll.x(j)};
+                        elem->physical_coordinates(xi, xy + 2 * g);
+                    }
+            }
+        }, 64);
     }
 
     FaceSpace::FaceSpace(const H1Space &fem_, int nf, const int *faces_)

@@ -194,6 +194,14 @@ def test_fused_helmholtz_linearity_symmetry_determinism_at_full_size(cuda, big, 
     P = cd.HelmholtzOperator(omega, a2, ax, fem, fs)
     P.action(x, Bx)
     assert float(torch.linalg.norm(Bx - Ax) / torch.linalg.norm(Ax)) < 1e-13
+    # and the lane form with the whole patch's metric block requested up front (one wavefront per SIMD; same arithmetic in
+    # the same order: bitwise the same vector)
+    monkeypatch.delenv("CUDDH_HELM_LANE")
+    monkeypatch.setenv("CUDDH_HELM_PRE", "1")
+    Q = cd.HelmholtzOperator(omega, a2, ax, fem, fs)
+    assert Q.kernel() == "helm_lane_kernel<4,5,8,NT=1,UG=0,PRE=1> pe=64"
+    Q.action(x, Bx)
+    assert torch.equal(Bx, Ax)
 
 
 def test_ddh_properties_at_full_size(cuda, big):

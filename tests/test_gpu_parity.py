@@ -353,13 +353,16 @@ def test_patch_sizes_agree(cuda, kind, nx, nb, monkeypatch):
     refA = oracle.helmholtz_apply(d, oracle.Stiffness(d), oracle.Mass(d, a2), oracle.FaceMass(ofs, ax), ofs, omega, xh)
     nqS, nqM = nb + 1, 2 + 3 * nb // 2
     got, seen = {}, set()
-    for pe in ("32", "64", "lane"):  # "lane": helm_lane_kernel (n_basis <= 4; chosen by size otherwise)
+    # "lane0": helm_lane_kernel (n_basis <= 4; chosen by size otherwise), the slice-by-slice chain large plans run by default;
+    # "lane": the same with the whole patch's metric block requested up front (CUDDH_HELM_PRE=1, one wavefront per SIMD)
+    for pe in ("32", "64", "lane", "lane0"):
         for affine in ("1", "0"):
             for nt in ("0", "1"):
-                if pe == "lane":
+                if pe.startswith("lane"):
                     monkeypatch.setenv("CUDDH_OP_PE", "64")
                     monkeypatch.delenv("CUDDH_HELM_PE", raising=False)
                     monkeypatch.setenv("CUDDH_HELM_LANE", "1")
+                    monkeypatch.setenv("CUDDH_HELM_PRE", "1" if pe == "lane" else "0")
                 else:
                     monkeypatch.setenv("CUDDH_OP_PE", pe)
                     monkeypatch.setenv("CUDDH_HELM_PE", pe)
@@ -381,15 +384,15 @@ def test_patch_sizes_agree(cuda, kind, nx, nb, monkeypatch):
                 assert A.fused()
                 # which instantiation ran
                 ug = int(kind == "structured" and affine == "1")  # uniform stiffness metric, read through scalar loads
-                ope = 64 if pe == "lane" else int(pe)
+                ope = 64 if pe.startswith("lane") else int(pe)
                 assert S.kernel() == f"op_patch_kernel<{nb},{nqS},0,NT={0 if ug else int(nt)},UG={ug},PEK={ope}> pe={ope}", S.kernel()
                 assert M.kernel() == f"op_patch_kernel<{nb},{nqM},1,NT={nt},UG=0,PEK={ope}> pe={ope}", M.kernel()  # a2 varies: never uniform
-                if pe == "lane" and nb <= 4 and (not ug or nb == 2):
-                    want = f"helm_lane_kernel<{nb},{nqS},{nqM},NT={nt},UG={ug}> pe=64"
+                if pe.startswith("lane") and nb <= 4 and (not ug or nb == 2):
+                    want = f"helm_lane_kernel<{nb},{nqS},{nqM},NT={nt},UG={ug}{',PRE=1' if pe == 'lane' else ''}> pe=64"
                 else:
                     # forced sizes apply to n_basis <= 4; affine plans are 64-element ones unless forced; a lane request that
                     # does not apply (affine n_basis 3, 4; n_basis 5) leaves the default size
-                    hpe = (int(pe) if pe != "lane" else (64 if ug else 32)) if nb <= 4 else 32
+                    hpe = (int(pe) if not pe.startswith("lane") else (64 if ug else 32)) if nb <= 4 else 32
                     want = f"helm_patch_kernel<{nb},{nqS},{nqM},NT={nt},UG={ug},PEK={hpe}> pe={hpe}"
                 assert A.kernel() == want, (A.kernel(), want)
                 seen.add(A.kernel())
@@ -404,10 +407,11 @@ def test_patch_sizes_agree(cuda, kind, nx, nb, monkeypatch):
     for key, val in got.items():
         for a, b in zip(val, base):
             assert rel(a, b) < 1e-13, key
-    if nb <= 4:  # the instantiations large general-geometry plans (the benchmark's) run
+    if nb <= 4:  # the instantiations large general-geometry plans (the benchmark's) run, and the chain form they replace
+        assert f"helm_lane_kernel<{nb},{nqS},{nqM},NT=1,UG=0,PRE=1> pe=64" in seen
         assert f"helm_lane_kernel<{nb},{nqS},{nqM},NT=1,UG=0> pe=64" in seen
     if nb == 2 and kind == "structured":
-        assert "helm_lane_kernel<2,3,5,NT=1,UG=1> pe=64" in seen
+        assert "helm_lane_kernel<2,3,5,NT=1,UG=1,PRE=1> pe=64" in seen
 
 
 # ------------------------------------------------------------------ fused Helmholtz apply
