@@ -188,6 +188,8 @@ def main() -> None:
     # Fallback (--exchange allreduce, or if the start-up cross-check below fails): replicated vectors, one all-reduce.
     sh_all = ShardedDDH(F, nd, rank, world, always_reduce=dist.is_initialized(), host_staging=staged)
     b = torch.zeros(n, dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    t_constructors = time.time() - t_setup  # mesh, spaces, coefficient projection, DDH constructor + kernel plan
     sh_all.rhs(f, b)
     exchange, exchange_note = ("allreduce" if world > 1 else "none"), ""
     sh = sh_all
@@ -327,7 +329,8 @@ def main() -> None:
                                       f"send/recv of {sum(i.numel() for i in getattr(sh, 'send_idx', {}).values()) * 4 / 1024:.0f} KiB to "
                                       f"{len(getattr(sh, 'send_idx', {}))} neighbour rank(s) per step (rank 0), all-reduce of each inner product"}[exchange]
                         + (f" [{exchange_note}]" if exchange_note else ""),
-            "setup_seconds": round(t_setup, 2),
+            "setup_seconds": round(t_constructors, 3),  # Mesh2D + H1Space + load vector / coefficient + DDH constructor + plan
+            "rhs_and_exchange_check_seconds": round(t_setup - t_constructors, 3),  # DDH::rhs (one pass of local solves) [+ N > 1 start-up check]
             "finite": finite,
         },
         "ddh_kernel": {

@@ -109,6 +109,7 @@ _sig("cuddh_hip_reciprocal_f64", ci, ci, vp, vp)
 _sig("cuddh_hip_gather_f64", ci, ci, vp, vp, vp, vp)
 _sig("cuddh_hip_scatter_add_f64", ci, ci, vp, vp, vp, vp)
 _sig("cuddh_hip_zero_indexed_f64", ci, ci, vp, vp, vp)
+_sig("cuddh_hip_element_metrics", ci, ci, ci, vp, vp, vp, vp, vp, vp)
 _sig("cuddh_hip_stiffness_setup", ci, ci, ci, vp, vp, vp, vp)
 _sig("cuddh_hip_stiffness_apply", ci, ci, ci, ci, vp, vp, vp, vp, cd, vp, vp, vp)
 _sig("cuddh_hip_mass_setup", ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp)
@@ -143,6 +144,9 @@ _sig("cuddh_basis_eval", ci, vp, ci, vp, vp)
 _sig("cuddh_basis_deriv", ci, vp, ci, vp, vp)
 _sig("cuddh_mesh_uniform_rect", vp, ci, cd, cd, ci, cd, cd)
 _sig("cuddh_mesh_from_vertices", vp, ci, vp, ci, vp)
+_sig("cuddh_mesh_load", vp, cp)
+_sig("cuddh_mesh_refined", vp, vp, ci)
+_sig("cuddh_mesh_partition", ci, vp, ci, vp)
 _sig("cuddh_mesh_destroy", None, vp)
 for _n in ("n_elem", "n_edges", "n_nodes", "n_boundary_edges"):
     _sig(f"cuddh_mesh_{_n}", ci, vp)

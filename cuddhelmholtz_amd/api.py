@@ -103,6 +103,21 @@ class Mesh2D:
         elems = np.ascontiguousarray(elems, dtype=np.int32)
         return Mesh2D(N.handle(lib.cuddh_mesh_from_vertices(xy.size // 2, _h(xy), elems.size // 4, _h(elems)), "Mesh2D.from_vertices"))
 
+    @staticmethod
+    def load(directory) -> "Mesh2D":
+        """the reference's text format: info.txt, coordinates.txt, elements.txt (tests/load_unstructured_square.cpp:11-55)"""
+        return Mesh2D(N.handle(lib.cuddh_mesh_load(str(directory).encode()), "Mesh2D.load"))
+
+    def refined(self, times: int = 1) -> "Mesh2D":
+        """uniform refinement: every quadrilateral -> 4 (edge midpoints + centroid), `times` rounds"""
+        return Mesh2D(N.handle(lib.cuddh_mesh_refined(self._h, int(times)), "Mesh2D.refined"))
+
+    def partition(self, n_parts: int) -> np.ndarray:
+        """element labels in [0, n_parts) for EnsembleSpace: compact, equally sized sets (centroid Morton order)"""
+        out = np.empty(self.n_elem(), dtype=np.int32)
+        N.check_capi(lib.cuddh_mesh_partition(self._h, int(n_parts), _h(out)), "Mesh2D.partition")
+        return out
+
     def n_elem(self):
         return lib.cuddh_mesh_n_elem(self._h)
 

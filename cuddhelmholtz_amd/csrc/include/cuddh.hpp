@@ -14,6 +14,7 @@
 #include "cuddh/basis.hpp"
 #include "cuddh/geometry.hpp"
 #include "cuddh/mesh.hpp"
+#include "cuddh/meshio.hpp"
 #include "cuddh/operator.hpp"
 #include "cuddh/spaces.hpp"
 #include "cuddh/ensemble.hpp"

@@ -38,9 +38,13 @@ namespace cuddh
             const double *physical_coordinates(MemorySpace m) const;
 
         private:
+            /// first request on the DEVICE: evaluated there from the elements' corners (no host table, no upload)
+            void on_device(host_device_dvec &out, int dim, int which) const;
+
             const Mesh2D &mesh;
             QuadratureRule quad;
             mutable host_device_dvec J, detJ, x;
+            mutable host_device_dvec corners, points; // (2, 4, n_elem) and the rule's nodes, device inputs of on_device()
         };
 
         /// Lazily evaluated per-edge metric arrays on a 1-D rule, for all edges of

@@ -6,6 +6,8 @@
 #define CUDDH_AMD_PARALLEL_HPP
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <cstddef>
 #include <cstdlib>
 #include <thread>
@@ -56,6 +58,20 @@ namespace cuddh
             for (auto &w : workers)
                 w.join();
         }
+        /// CUDDH_SETUP_TIMING=1 prints the wall time of each constructor phase (host work, once per solver)
+        struct PhaseTimer
+        {
+            const bool on = std::getenv("CUDDH_SETUP_TIMING") != nullptr;
+            std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+            void lap(const char *what)
+            {
+                if (!on)
+                    return;
+                const auto t1 = std::chrono::steady_clock::now();
+                std::fprintf(stderr, "[cuddh setup] %-36s %8.3f s\n", what, std::chrono::duration<double>(t1 - t0).count());
+                t0 = t1;
+            }
+        };
     } // namespace detail
 } // namespace cuddh
 

@@ -31,6 +31,44 @@ namespace
         return e < 1 ? 1 : e;
     }
 
+    // ------------------------------------------------------------ element metrics on the tensor grid of a 1-D rule
+    // The bilinear map of source/Element.cpp:5-36 evaluated at (q[i], q[j]) of every element: Jacobian [x_xi, y_xi, x_eta,
+    // y_eta], its determinant, the physical point.  The reference tabulates these on the host and mirrors them
+    // (source/Mesh2D.cpp:173-227); at 1024^2 elements that is 0.5 GB of host work and upload per rule.
+    __global__ void __launch_bounds__(BLOCK) element_metrics_kernel(long long n_pts, int n, const double *__restrict__ corners, const double *__restrict__ q,
+                                                                    double *__restrict__ J, double *__restrict__ detJ, double *__restrict__ x)
+    {
+        for (long long t = blockIdx.x * (long long)BLOCK + threadIdx.x; t < n_pts; t += (long long)gridDim.x * BLOCK)
+        {
+            const long long el = t / (n * n);
+            const int loc = static_cast<int>(t - el * (n * n));
+            const double s = q[loc % n], e = q[loc / n];
+            const double *c = corners + 8 * el; // (2, 4): corners counter-clockwise
+            double j4[4];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+            {
+                j4[a] = 0.25 * ((1 - e) * (c[2 + a] - c[0 + a]) + (1 + e) * (c[4 + a] - c[6 + a]));
+                j4[2 + a] = 0.25 * ((1 - s) * (c[6 + a] - c[0 + a]) + (1 + s) * (c[4 + a] - c[2 + a]));
+            }
+            if (J)
+            {
+                J[4 * t] = j4[0];
+                J[4 * t + 1] = j4[1];
+                J[4 * t + 2] = j4[2];
+                J[4 * t + 3] = j4[3];
+            }
+            if (detJ)
+                detJ[t] = j4[0] * j4[3] - j4[1] * j4[2];
+            if (x)
+            {
+                const double N0 = 0.25 * (1 - s) * (1 - e), N1 = 0.25 * (1 + s) * (1 - e), N2 = 0.25 * (1 + s) * (1 + e), N3 = 0.25 * (1 - s) * (1 + e);
+                x[2 * t] = ((c[0] * N0 + c[2] * N1) + c[4] * N2) + c[6] * N3;
+                x[2 * t + 1] = ((c[1] * N0 + c[3] * N1) + c[5] * N2) + c[7] * N3;
+            }
+        }
+    }
+
     // ------------------------------------------------------------ geometric factors (K2)
     __global__ void __launch_bounds__(BLOCK) stiffness_setup_kernel(long long n_pts, int nq, const double *__restrict__ w, const double *__restrict__ J,
                                                                     double *__restrict__ G)
@@ -318,6 +356,15 @@ namespace
 
 extern "C"
 {
+    int cuddh_hip_element_metrics(int n_elem, int n, const double *corners, const double *q, double *J, double *detJ, double *x, void *stream)
+    {
+        const long long n_pts = (long long)n_elem * n * n;
+        if (n_pts <= 0)
+            return 0;
+        hipLaunchKernelGGL(element_metrics_kernel, dim3(stream_grid(n_pts, BLOCK)), dim3(BLOCK), 0, as_stream(stream), n_pts, n, corners, q, J, detJ, x);
+        return launch_status();
+    }
+
     int cuddh_hip_stiffness_setup(int n_elem, int nq, const double *w, const double *J, double *G, void *stream)
     {
         const long long n_pts = (long long)n_elem * nq * nq;

@@ -1,5 +1,6 @@
 // C handle layer (include/cuddh_capi.h).  Compiled as HIP: the built-in integrands
 // are device functors fed to the LinearFunctional header templates.
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -206,6 +207,26 @@ extern "C"
     void *cuddh_mesh_from_vertices(int n_pts, const double *h_xy, int n_elem, const int *h_elems)
     {
         return guarded_new<Mesh2D>([&] { return new Mesh2D(Mesh2D::from_vertices(n_pts, h_xy, n_elem, h_elems)); });
+    }
+    void *cuddh_mesh_load(const char *dir)
+    {
+        return guarded_new<Mesh2D>([&] { return new Mesh2D(load_mesh(dir)); });
+    }
+    void *cuddh_mesh_refined(void *m, int times)
+    {
+        return guarded_new<Mesh2D>([&]
+        {
+            const QuadMeshData fine = refine_quads(mesh_data(*static_cast<Mesh2D *>(m)), times);
+            return new Mesh2D(Mesh2D::from_vertices(fine.n_pts(), fine.xy.data(), fine.n_elem(), fine.elems.data()));
+        });
+    }
+    int cuddh_mesh_partition(void *m, int n_parts, int *h_labels)
+    {
+        return guarded([&]
+        {
+            const std::vector<int> labels = partition_elements(*static_cast<Mesh2D *>(m), n_parts);
+            std::copy(labels.begin(), labels.end(), h_labels);
+        });
     }
     void cuddh_mesh_destroy(void *m) { delete static_cast<Mesh2D *>(m); }
     int cuddh_mesh_n_elem(void *m) { return static_cast<Mesh2D *>(m)->n_elem(); }

@@ -34,21 +34,6 @@ namespace cuddh
             }
         } // namespace
 
-        // CUDDH_SETUP_TIMING=1 prints the wall time of each constructor phase (host work, once per solver)
-        struct PhaseTimer
-        {
-            const bool on = std::getenv("CUDDH_SETUP_TIMING") != nullptr;
-            std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
-            void lap(const char *what)
-            {
-                if (!on)
-                    return;
-                const auto t1 = std::chrono::steady_clock::now();
-                std::fprintf(stderr, "[cuddh setup] %-28s %8.3f s\n", what, std::chrono::duration<double>(t1 - t0).count());
-                t0 = t1;
-            }
-        };
-
         template <typename Real>
         DDHCore<Real>::DDHCore(double omega_, const double *h_a, const H1Space &fem, int nx, int ny, int kernel)
             : g_ndof(fem.size()), g_elem(fem.mesh().n_elem()), n_basis(fem.basis().size()), omega(omega_), fem_mesh(&fem.mesh()),
@@ -191,8 +176,14 @@ namespace cuddh
                     hD[i] = static_cast<Real>(Dd[i]);
             }
 
-            const auto &metrics = fem.mesh().element_metrics(q);
-            auto detJ = reshape(metrics.measures(MemorySpace::HOST), nb, nb, g_elem);
+            // det J at the GLL points, evaluated where it is used (the reference reads the tabulated array,
+            // source/DDH.cpp:551-552; tabulating 16 n_elem doubles on the host costs more than the two loops that read them)
+            const Mesh2D &the_mesh = fem.mesh();
+            auto detJ = [&](int i, int j, int el)
+            {
+                const double xi[2] = {q.x(i), q.x(j)};
+                return the_mesh.element(el)->measure(xi);
+            };
             auto fem_gi = fem.global_indices(MemorySpace::HOST);
 
             timer.lap("element metrics");
@@ -316,6 +307,7 @@ namespace cuddh
         {
             if (plan)
                 return;
+            PhaseTimer timer;
             const int nb = n_basis;
             const QuadratureRule &q = fem_basis->quadrature();
 
@@ -329,6 +321,7 @@ namespace cuddh
             geom_setup<Real>(n_domains, mx_elem_per_dom, g_elem, nb, efem->n_elems(MemorySpace::DEVICE),
                              efem->elements(MemorySpace::DEVICE), w.device_read(), d_J, _g_tensor.device_write());
             check_hip(cuddh_hip_stream_sync(stream()), "DDH geometric factors");
+            timer.lap("plan: Jacobians + geometric factors");
 
             cuddh_ddh_desc d;
             d.g_ndof = g_ndof;
@@ -355,8 +348,11 @@ namespace cuddh
             d.wh_filter = _wh_filter.device_read();
             d.cs = _cs.device_read();
             d.sn = _sn.device_read();
+            check_hip(cuddh_hip_stream_sync(stream()), "DDH table upload");
+            timer.lap("plan: table uploads");
             check_hip(cuddh_hip_ddh_plan_create(&plan, &d, std::is_same_v<Real, double> ? 1 : 0, requested_kernel),
                       "DDH plan");
+            timer.lap("plan: structure check + kernel tables");
         }
 
         template <typename Real>

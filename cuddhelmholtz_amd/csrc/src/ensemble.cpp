@@ -91,6 +91,8 @@ namespace cuddh
             /// true when the key was not present
             bool insert(std::uint64_t k)
             {
+                if (2 * (used + 1) > cap)
+                    grow();
                 std::size_t h = static_cast<std::size_t>((k * 0x9E3779B97F4A7C15ull) >> 17) & (cap - 1);
                 while (slot[h] != EMPTY)
                 {
@@ -99,10 +101,24 @@ namespace cuddh
                     h = (h + 1) & (cap - 1);
                 }
                 slot[h] = k;
+                ++used;
                 return true;
             }
 
         private:
+            void grow()
+            {
+                std::vector<std::uint64_t> old;
+                old.swap(slot);
+                cap <<= 1;
+                slot.assign(cap, EMPTY);
+                used = 0;
+                for (const std::uint64_t k : old)
+                    if (k != EMPTY)
+                        insert(k);
+            }
+
+            std::size_t used = 0;
             static constexpr std::uint64_t EMPTY = ~0ull;
             std::size_t cap;
             std::vector<std::uint64_t> slot;
@@ -116,6 +132,7 @@ namespace cuddh
         const Mesh2D &mesh = fem.mesh();
         const int nel = mesh.n_elem();
         const int nb = n_basis, nn = nb * nb;
+        detail::PhaseTimer timer;
 
         // ---- elements of each subspace, in increasing global order (counting sort)
         int *h_s_elems = s_elems.host_write();
@@ -141,6 +158,7 @@ namespace cuddh
         for (int el = 0; el < nel; ++el)
             h_elems[local_elem[el] + static_cast<std::size_t>(mx_elems) * labels[el]] = el;
 
+        timer.lap("EnsembleSpace: elements");
         // ---- boundary faces of each subspace (global edge order) and the faces two subspaces share
         const int g_edges = mesh.n_edges();
         int *h_s_faces = s_faces.host_write();
@@ -197,6 +215,7 @@ namespace cuddh
             for (int f = 0; f < h_s_faces[p]; ++f)
                 h_faces[f + static_cast<std::size_t>(mx_faces) * p] = sub_faces[face_off[p] + f].edge;
 
+        timer.lap("EnsembleSpace: faces");
         // ---- subspace dof numbering: first touch over (el, j, i); subspaces are independent of each other
         sI.resize(nn * mx_elems * n_spaces);
         int *h_sI = sI.host_write();
@@ -245,6 +264,7 @@ namespace cuddh
             }
         }, 16);
 
+        timer.lap("EnsembleSpace: subspace dofs");
         // ---- face-space numbering: first touch over (face, i)
         fI.resize(nb * mx_faces * n_spaces);
         int *h_fI = fI.host_write();
@@ -309,24 +329,44 @@ namespace cuddh
             }
         }, 16);
 
+        timer.lap("EnsembleSpace: face dofs");
         // ---- shared dof pairs, unique per (unordered subspace pair, dof of the lower-numbered subspace), in the order the
         // shared faces (global edge order) reach them
-        std::vector<std::array<int, 4>> pairs;
-        pairs.reserve(shared_faces.size() * nb);
-        KeySet seen(shared_faces.size() * nb);
-        for (const auto &sfc : shared_faces)
+        // A key can only repeat among the faces of ONE subspace pair, so the candidates are split by their lower subspace into
+        // ranges, one per thread; every range walks the shared faces in order (first occurrence wins, as in the serial loop)
+        // with a set small enough to stay in cache, and the survivors are collected in face order afterwards.
+        const std::size_t n_cand = shared_faces.size() * nb;
+        std::vector<unsigned char> keep(n_cand, 0);
+        const int CR = detail::chunk_count(static_cast<std::size_t>(n_spaces), 64);
+        detail::parallel_for(static_cast<std::size_t>(n_spaces), [&](std::size_t lo0, std::size_t lo1, int)
         {
-            const int S0 = sfc[0], S1 = sfc[1], f0 = sfc[2], f1 = sfc[3];
-            const std::uint64_t lo = std::min(S0, S1), hi = std::max(S0, S1);
-            const std::uint64_t pair_id = lo + static_cast<std::uint64_t>(n_spaces) * hi;
-            for (int i = 0; i < nb; ++i)
+            KeySet seen(n_cand / static_cast<std::size_t>(CR) + 64);
+            for (std::size_t t = 0; t < shared_faces.size(); ++t)
             {
-                const int j0 = h_fI[i + nb * (f0 + static_cast<std::size_t>(mx_faces) * S0)];
-                const int j1 = h_fI[i + nb * (f1 + static_cast<std::size_t>(mx_faces) * S1)];
-                const std::uint64_t dof_of_lower = static_cast<std::uint64_t>(S0 < S1 ? j0 : j1);
-                if (seen.insert(pair_id * static_cast<std::uint64_t>(mx_fdof + 1) + dof_of_lower))
-                    pairs.push_back({S0, S1, j0, j1});
+                const auto &sfc = shared_faces[t];
+                const int S0 = sfc[0], S1 = sfc[1], f0 = sfc[2], f1 = sfc[3];
+                const std::uint64_t lo = std::min(S0, S1), hi = std::max(S0, S1);
+                if (lo < lo0 || lo >= lo1)
+                    continue;
+                const std::uint64_t pair_id = lo + static_cast<std::uint64_t>(n_spaces) * hi;
+                for (int i = 0; i < nb; ++i)
+                {
+                    const int j = S0 < S1 ? h_fI[i + nb * (f0 + static_cast<std::size_t>(mx_faces) * S0)]
+                                          : h_fI[i + nb * (f1 + static_cast<std::size_t>(mx_faces) * S1)];
+                    keep[t * nb + i] = seen.insert(pair_id * static_cast<std::uint64_t>(mx_fdof + 1) + static_cast<std::uint64_t>(j)) ? 1 : 0;
+                }
             }
+        }, 64);
+        std::vector<std::array<int, 4>> pairs;
+        pairs.reserve(n_cand);
+        for (std::size_t t = 0; t < shared_faces.size(); ++t)
+        {
+            const auto &sfc = shared_faces[t];
+            const int S0 = sfc[0], S1 = sfc[1], f0 = sfc[2], f1 = sfc[3];
+            for (int i = 0; i < nb; ++i)
+                if (keep[t * nb + i])
+                    pairs.push_back({S0, S1, h_fI[i + nb * (f0 + static_cast<std::size_t>(mx_faces) * S0)],
+                                     h_fI[i + nb * (f1 + static_cast<std::size_t>(mx_faces) * S1)]});
         }
 
         n_shared_dofs = static_cast<int>(pairs.size());
@@ -335,5 +375,6 @@ namespace cuddh
         for (int k = 0; k < n_shared_dofs; ++k)
             for (int c = 0; c < 4; ++c)
                 h_cmap[c + 4 * k] = pairs[k][c];
+        timer.lap("EnsembleSpace: shared pairs");
     }
 } // namespace cuddh

@@ -2,7 +2,9 @@
 #include "cuddh/mesh.hpp"
 
 #include "cuddh/error.hpp"
+#include "cuddh/launch.hpp"
 #include "cuddh/parallel.hpp"
+#include "cuddh_hip.h"
 
 #include <algorithm>
 #include <cstdint>
@@ -126,6 +128,7 @@ namespace cuddh
         auto vx = [&](int i) { return ax + dx * i; };
         auto vy = [&](int j) { return ay + dy * j; };
 
+        detail::PhaseTimer timer;
         Mesh2D mesh;
         mesh._nodes.resize(static_cast<std::size_t>(npx) * npy);
         mesh._elements.resize(static_cast<std::size_t>(nx) * ny);
@@ -155,6 +158,7 @@ namespace cuddh
                         nd.connected_elements.push_back({0, i + nx * j});
                 }
         }, 8);
+        timer.lap("mesh: nodes");
 
         detail::parallel_for(static_cast<std::size_t>(ny), [&](std::size_t j0, std::size_t j1, int)
         {
@@ -205,7 +209,9 @@ namespace cuddh
                 }
             }
         }, 8);
+        timer.lap("mesh: elements and edges");
         mesh.classify();
+        timer.lap("mesh: boundary/interior lists");
         return mesh;
     }
 
@@ -275,8 +281,41 @@ namespace cuddh
         }
     } // namespace
 
+    void Mesh2D::ElementMetricCollection::on_device(host_device_dvec &out, int dim, int which) const
+    {
+        const int m = quad.size(), nel = mesh.n_elem();
+        if (corners.size() == 0)
+        {
+            corners.resize(8 * nel);
+            double *c = corners.host_write();
+            detail::parallel_for(static_cast<std::size_t>(nel), [&](std::size_t e0, std::size_t e1, int)
+            {
+                for (std::size_t el = e0; el < e1; ++el)
+                {
+                    const QuadElement &q = mesh._elements[el];
+                    for (int k = 0; k < 4; ++k)
+                    {
+                        c[8 * el + 2 * k] = q.corner(k)[0];
+                        c[8 * el + 2 * k + 1] = q.corner(k)[1];
+                    }
+                }
+            });
+            points.resize(m);
+            double *p = points.host_write();
+            for (int i = 0; i < m; ++i)
+                p[i] = quad.x(i);
+        }
+        out.resize(dim * m * m * nel);
+        double *d = out.device_write();
+        detail::check_hip(cuddh_hip_element_metrics(nel, m, corners.device_read(), points.device_read(), which == 0 ? d : nullptr,
+                                                    which == 1 ? d : nullptr, which == 2 ? d : nullptr, stream()),
+                          "element metrics");
+    }
+
     const double *Mesh2D::ElementMetricCollection::jacobians(MemorySpace m) const
     {
+        if (J.size() == 0 && m == MemorySpace::DEVICE)
+            on_device(J, 4, 0);
         if (J.size() == 0)
             tabulate_elements(J, 4, mesh, quad, [](double *o, const Element *e, const double *xi) { e->jacobian(xi, o); });
         return J.read(m);
@@ -284,6 +323,8 @@ namespace cuddh
 
     const double *Mesh2D::ElementMetricCollection::measures(MemorySpace m) const
     {
+        if (detJ.size() == 0 && m == MemorySpace::DEVICE)
+            on_device(detJ, 1, 1);
         if (detJ.size() == 0)
             tabulate_elements(detJ, 1, mesh, quad, [](double *o, const Element *e, const double *xi) { *o = e->measure(xi); });
         return detJ.read(m);
@@ -291,6 +332,8 @@ namespace cuddh
 
     const double *Mesh2D::ElementMetricCollection::physical_coordinates(MemorySpace m) const
     {
+        if (x.size() == 0 && m == MemorySpace::DEVICE)
+            on_device(x, 2, 2);
         if (x.size() == 0)
             tabulate_elements(x, 2, mesh, quad, [](double *o, const Element *e, const double *xi) { e->physical_coordinates(xi, o); });
         return x.read(m);

@@ -42,6 +42,7 @@ namespace cuddh
         const int N = nb * nb * n_elem;
         int *I = _I.host_write();
 
+        detail::PhaseTimer timer;
         // owner[v] = flat index of the node v is a copy of (-1: v owns itself).  The loops below are the reference's
         // (source/H1Space.cpp:47-106) cut into contiguous ranges for the set-up threads; every entry has one writer.
         std::vector<int> owner(N, -1);
@@ -79,6 +80,7 @@ namespace cuddh
             }
         });
 
+        timer.lap("H1Space: owners");
         // owners are numbered in increasing flat index: count per range, prefix sum, assign; then the copies
         const int C = detail::chunk_count(static_cast<std::size_t>(N));
         std::vector<int> first_id(C + 1, 0);
@@ -106,6 +108,7 @@ namespace cuddh
                     I[v] = I[owner[v]];
         });
 
+        timer.lap("H1Space: numbering");
         // collocation points: the reference overwrites a shared dof's point element after element, the highest element wins
         // (source/H1Space.cpp:108-126).  In parallel: each range of elements first stamps the dofs it touches with its range
         // number (highest wins), then writes only the dofs it won, in element order -- the same winner as the serial loop.
@@ -145,6 +148,7 @@ namespace cuddh
                     }
             }
         }, 64);
+        timer.lap("H1Space: collocation points");
     }
 
     FaceSpace::FaceSpace(const H1Space &fem_, int nf, const int *faces_)

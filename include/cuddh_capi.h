@@ -32,6 +32,11 @@ int cuddh_basis_deriv(void *basis, int m, const double *h_x, double *h_D); /* D 
 /* ---- mesh (reference include/Mesh2D.hpp) */
 void *cuddh_mesh_uniform_rect(int nx, double ax, double bx, int ny, double ay, double by);
 void *cuddh_mesh_from_vertices(int n_pts, const double *h_xy, int n_elem, const int *h_elems);
+/* mesh ingestion (csrc/include/cuddh/meshio.hpp): the reference's text format (tests/load_unstructured_square.cpp:11-55),
+ * `times` rounds of uniform refinement of an existing mesh, and labels for EnsembleSpace (n_parts compact element sets) */
+void *cuddh_mesh_load(const char *dir);
+void *cuddh_mesh_refined(void *mesh, int times);
+int cuddh_mesh_partition(void *mesh, int n_parts, int *h_labels); /* (n_elem) */
 void cuddh_mesh_destroy(void *mesh);
 int cuddh_mesh_n_elem(void *mesh);
 int cuddh_mesh_n_edges(void *mesh);

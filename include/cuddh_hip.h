@@ -99,6 +99,10 @@ int cuddh_hip_zero_indexed_f64(int n, const int *proj, double *x, void *stream);
  * Shapes: P,D (nq,nb); I (nb,nb,n_elem); J (2,2,nq,nq,n_elem); detJ (nq,nq,n_elem);
  * G (3,nq,nq,n_elem); a (nq,nq,n_elem); w (nq). */
 
+/* source/Mesh2D.cpp:173-227 + source/Element.cpp:5-36: the metric arrays of Mesh2D::ElementMetricCollection on the tensor
+ * grid of a 1-D rule q (n points), computed on the device from the elements' corners (2, 4, n_elem; counter-clockwise):
+ * J (2,2,n,n,n_elem), detJ (n,n,n_elem), x (2,n,n,n_elem); any output may be NULL. */
+int cuddh_hip_element_metrics(int n_elem, int n, const double *corners, const double *q, double *J, double *detJ, double *x, void *stream);
 /* source/StiffnessMatrix.cpp:5-38  (setup_geometric_factors) */
 int cuddh_hip_stiffness_setup(int n_elem, int nq, const double *w, const double *J, double *G, void *stream);
 /* source/StiffnessMatrix.cpp:83-205  y[I] += c * S x */

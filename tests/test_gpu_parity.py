@@ -791,6 +791,52 @@ def test_fused_apply_on_refined_unstructured_mesh(cuda):
     assert rel(yS.cpu().numpy(), oracle.Stiffness(d).apply(xh[: d.ndof])) < 1e-12
 
 
+@pytest.mark.parametrize("nb", [6, 7])
+def test_config5_unstructured_high_order_through_the_product(cuda, nb):
+    """BASELINE config 5 as far as the reference defines it: meshes/unstructured_square read by the product's
+    loader, refined by the product (r = 1: 476 quads >= 256 partitions), "p = 6" (n_basis 6 and, degree reading,
+    7) on the matrix-core kernels, omega = 16 pi, 256 subdomains from the product's partitioner: fused Helmholtz apply,
+    stiffness and weighted mass against the oracle, EnsembleSpace tables identical to the oracle's."""
+    import torch
+
+    import cuddhelmholtz_amd as cd
+    from conftest import GOLDEN
+
+    pm = cd.Mesh2D.load(GOLDEN / "unstructured_square").refined(1)
+    assert pm.n_elem() == 476
+    om = oracle.Mesh(pm.vertices(), pm.elements())
+    fem = cd.H1Space(pm, cd.Basis(nb))
+    d = oracle.Discretization(om, nb)
+    assert fem.size() == d.ndof
+    faces = pm.boundary_edges()
+    fs = cd.FaceSpace(fem, faces)
+    ofs = oracle.FaceSpaceO(d, list(faces))
+    rng = np.random.default_rng(500 + nb)
+    a2, ax = 0.5 + rng.random(d.ndof), 0.5 + rng.random(ofs.size)
+    omega = 16 * math.pi
+    A = cd.HelmholtzOperator(omega, to_dev(torch, a2, cuda), to_dev(torch, ax, cuda), fem, fs)
+    assert A.fused() and A.kernel().startswith(f"helm_mfma_kernel<{nb},")
+    xh = rng.standard_normal(2 * d.ndof)
+    x = to_dev(torch, xh, cuda)
+    y = torch.empty_like(x)
+    A.action(x, y)
+    S, M = oracle.Stiffness(d), oracle.Mass(d, a2)
+    ref = oracle.helmholtz_apply(d, S, M, oracle.FaceMass(ofs, ax), ofs, omega, xh)
+    assert rel(y.cpu().numpy(), ref) < 1e-12
+    yr = torch.empty(d.ndof, dtype=torch.float64, device=cuda)
+    Sp, Mp = cd.StiffnessMatrix(fem), cd.MassMatrix(fem, to_dev(torch, a2, cuda))
+    Sp.action(x[: d.ndof], yr)
+    assert rel(yr.cpu().numpy(), S.apply(xh[: d.ndof])) < 1e-12 and Sp.kernel().startswith(f"op_mfma_kernel<{nb},")
+    Mp.action(x[: d.ndof], yr)
+    assert rel(yr.cpu().numpy(), M.apply(xh[: d.ndof])) < 1e-12
+    # 256 subdomains
+    labels = pm.partition(256)
+    E = cd.EnsembleSpace(fem, 256, labels)
+    ref_e = oracle.ensemble(om, d.I, 256, labels)
+    for name, want in [("gI", ref_e.gI), ("sI", ref_e.sI), ("fI", ref_e.fI), ("pI", ref_e.pI), ("cmap", ref_e.cmap), ("faces", ref_e.faces)]:
+        assert np.array_equal(E.array(name), want), name
+
+
 @pytest.mark.parametrize("nx,nb", [(1, 2), (1, 4), (2, 3), (3, 5), (6, 4), (7, 6), (1, 8), (5, 7)])
 def test_operators_on_tiny_meshes(cuda, nx, nb):
     """Edge cases of the patch plans: a single element, a single (partly filled) patch, no border dofs at all, an odd
