@@ -75,6 +75,8 @@ _sig("cuddh_hip_malloc_zeroed", ci, C.POINTER(vp), cs)
 _sig("cuddh_hip_free", ci, vp)
 _sig("cuddh_hip_copy_h2d", ci, vp, vp, cs)
 _sig("cuddh_hip_copy_d2h", ci, vp, vp, cs)
+_sig("cuddh_hip_copy_h2d_on", ci, vp, vp, cs, vp)
+_sig("cuddh_hip_copy_d2h_on", ci, vp, vp, cs, vp)
 _sig("cuddh_hip_copy_d2d", ci, vp, vp, cs, vp)
 _sig("cuddh_hip_memset_zero", ci, vp, cs, vp)
 _sig("cuddh_hip_stream_sync", ci, vp)

@@ -18,14 +18,24 @@ from . import _native as N
 lib = N.lib
 
 
-def _ptr(t):
-    """Device pointer of a torch tensor (None -> NULL)."""
+def _ptr(t, dtype=None, numel=None, what="tensor"):
+    """Device pointer of a torch tensor (None -> NULL).  dtype: "f64" / "f32" / a torch dtype the entry point reads or
+    writes; numel: the least number of elements it touches.  A tensor of another type or a shorter one would otherwise become
+    an out-of-bounds device access behind the C ABI instead of a Python error."""
     if t is None:
         return None
     if not t.is_cuda:
-        raise ValueError("expected a CUDA tensor")
+        raise ValueError(f"{what}: expected a CUDA tensor")
     if not t.is_contiguous():
-        raise ValueError("expected a contiguous tensor")
+        raise ValueError(f"{what}: expected a contiguous tensor")
+    if dtype is not None:
+        import torch
+
+        want = {"f64": torch.float64, "f32": torch.float32}.get(dtype, dtype)
+        if t.dtype != want:
+            raise ValueError(f"{what}: expected dtype {want}, got {t.dtype}")
+    if numel is not None and t.numel() < numel:
+        raise ValueError(f"{what}: expected at least {numel} elements, got {t.numel()}")
     return C.c_void_p(t.data_ptr())
 
 
@@ -213,13 +223,13 @@ class FaceSpace:
         return p
 
     def restrict(self, x, y):
-        N.check_capi(lib.cuddh_facespace_restrict(self._h, _ptr(x), _ptr(y)), "restrict")
+        N.check_capi(lib.cuddh_facespace_restrict(self._h, _ptr(x, "f64", self.fem.size(), "x"), _ptr(y, "f64", self.size(), "y")), "restrict")
 
     def prolong(self, x, y):
-        N.check_capi(lib.cuddh_facespace_prolong(self._h, _ptr(x), _ptr(y)), "prolong")
+        N.check_capi(lib.cuddh_facespace_prolong(self._h, _ptr(x, "f64", self.size(), "x"), _ptr(y, "f64", self.fem.size(), "y")), "prolong")
 
     def orth(self, x):
-        N.check_capi(lib.cuddh_facespace_orth(self._h, _ptr(x)), "orth")
+        N.check_capi(lib.cuddh_facespace_orth(self._h, _ptr(x, "f64", self.fem.size(), "x")), "orth")
 
 
 class EnsembleSpace:
@@ -264,9 +274,10 @@ class EnsembleSpace:
 class _Operator:
     """y = A x (`action(x, y)`) and y += c A x (`action(c, x, y)`) on device vectors."""
 
-    def __init__(self, handle, keepalive=()):
+    def __init__(self, handle, keepalive=(), n=None):
         self._h = handle
         self._keep = keepalive
+        self._n = n  # length of the vectors action() reads and writes (None: not checked)
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
@@ -286,46 +297,46 @@ class _Operator:
     def action(self, *args):
         if len(args) == 2:
             x, y = args
-            N.check_capi(lib.cuddh_operator_apply(self._h, _ptr(x), _ptr(y)), "action")
+            N.check_capi(lib.cuddh_operator_apply(self._h, _ptr(x, "f64", self._n, "x"), _ptr(y, "f64", self._n, "y")), "action")
         else:
             c, x, y = args
-            N.check_capi(lib.cuddh_operator_apply_add(self._h, float(c), _ptr(x), _ptr(y)), "action")
+            N.check_capi(lib.cuddh_operator_apply_add(self._h, float(c), _ptr(x, "f64", self._n, "x"), _ptr(y, "f64", self._n, "y")), "action")
 
 
 class StiffnessMatrix(_Operator):
     def __init__(self, fem: H1Space, nq: int = 0):
-        super().__init__(N.handle(lib.cuddh_stiffness_create(fem._h, nq), "StiffnessMatrix"), (fem,))
+        super().__init__(N.handle(lib.cuddh_stiffness_create(fem._h, nq), "StiffnessMatrix"), (fem,), fem.size())
 
 
 class MassMatrix(_Operator):
     def __init__(self, fem: H1Space, a=None):
-        super().__init__(N.handle(lib.cuddh_mass_create(fem._h, _ptr(a)), "MassMatrix"), (fem, a))
+        super().__init__(N.handle(lib.cuddh_mass_create(fem._h, _ptr(a, "f64", fem.size(), "a")), "MassMatrix"), (fem, a), fem.size())
 
 
 class DiagInvMassMatrix(_Operator):
     def __init__(self, fem: H1Space, a=None):
-        super().__init__(N.handle(lib.cuddh_diaginv_mass_create(fem._h, _ptr(a)), "DiagInvMassMatrix"), (fem, a))
+        super().__init__(N.handle(lib.cuddh_diaginv_mass_create(fem._h, _ptr(a, "f64", fem.size(), "a")), "DiagInvMassMatrix"), (fem, a), fem.size())
 
 
 class FaceMassMatrix(_Operator):
     def __init__(self, fs: FaceSpace, a=None):
-        super().__init__(N.handle(lib.cuddh_facemass_create(fs._h, _ptr(a)), "FaceMassMatrix"), (fs, a))
+        super().__init__(N.handle(lib.cuddh_facemass_create(fs._h, _ptr(a, "f64", fs.size(), "a")), "FaceMassMatrix"), (fs, a), fs.size())
 
 
 class DiagInvFaceMassMatrix(_Operator):
     def __init__(self, fs: FaceSpace, a=None):
-        super().__init__(N.handle(lib.cuddh_diaginv_facemass_create(fs._h, _ptr(a)), "DiagInvFaceMassMatrix"), (fs, a))
+        super().__init__(N.handle(lib.cuddh_diaginv_facemass_create(fs._h, _ptr(a, "f64", fs.size(), "a")), "DiagInvFaceMassMatrix"), (fs, a), fs.size())
 
 
 class HelmholtzOperator(_Operator):
     """Fused [u;v] -> [Au;Av] of reference examples/Helmholtz.hpp:28-56."""
 
     def __init__(self, omega: float, a2x, ax, fem: H1Space, fs: FaceSpace):
-        super().__init__(N.handle(lib.cuddh_helmholtz_create(float(omega), _ptr(a2x), _ptr(ax), fem._h, fs._h), "HelmholtzOperator"),
-                         (fem, fs, a2x, ax))
+        super().__init__(N.handle(lib.cuddh_helmholtz_create(float(omega), _ptr(a2x, "f64", fem.size(), "a2x"), _ptr(ax, "f64", fs.size(), "ax"), fem._h, fs._h),
+                                  "HelmholtzOperator"), (fem, fs, a2x, ax), 2 * fem.size())
 
     def action_unfused(self, x, y):
-        N.check_capi(lib.cuddh_helmholtz_apply_unfused(self._h, _ptr(x), _ptr(y)), "action_unfused")
+        N.check_capi(lib.cuddh_helmholtz_apply_unfused(self._h, _ptr(x, "f64", self._n, "x"), _ptr(y, "f64", self._n, "y")), "action_unfused")
 
     def fused(self) -> bool:
         return bool(lib.cuddh_helmholtz_is_fused(self._h))
@@ -422,19 +433,22 @@ class DDH:
         return out
 
     def rhs(self, f, b):
-        N.check_capi(lib.cuddh_ddh_rhs(self._h, _ptr(f), _ptr(b)), "DDH.rhs")
+        N.check_capi(lib.cuddh_ddh_rhs(self._h, _ptr(f, "f64", 2 * self.fem.size(), "f"), _ptr(b, self.trace_dtype, self.size(), "b")), "DDH.rhs")
 
     def postprocess(self, lam, f, u):
-        N.check_capi(lib.cuddh_ddh_postprocess(self._h, _ptr(lam), _ptr(f), _ptr(u)), "DDH.postprocess")
+        N.check_capi(lib.cuddh_ddh_postprocess(self._h, _ptr(lam, self.trace_dtype, self.size(), "lambda"), _ptr(f, "f64", 2 * self.fem.size(), "f"),
+                                               _ptr(u, "f64", 2 * self.fem.size(), "u")), "DDH.postprocess")
 
     def action(self, x, y):
-        N.check_capi(lib.cuddh_ddh_action(self._h, _ptr(x), _ptr(y)), "DDH.action")
+        N.check_capi(lib.cuddh_ddh_action(self._h, _ptr(x, self.trace_dtype, self.size(), "x"), _ptr(y, self.trace_dtype, self.size(), "y")), "DDH.action")
 
     def local_traces(self, d0, d1, f, lam, update):
-        N.check_capi(lib.cuddh_ddh_local_traces(self._h, d0, d1, _ptr(f), _ptr(lam), _ptr(update)), "DDH.local_traces")
+        N.check_capi(lib.cuddh_ddh_local_traces(self._h, d0, d1, _ptr(f, "f64", 2 * self.fem.size(), "f"), _ptr(lam, self.trace_dtype, self.size(), "lambda"),
+                                                 _ptr(update, self.trace_dtype, self.size(), "update")), "DDH.local_traces")
 
     def local_solution(self, d0, d1, lam, f, u, zero_u=True):
-        N.check_capi(lib.cuddh_ddh_local_solution(self._h, d0, d1, _ptr(lam), _ptr(f), _ptr(u), int(zero_u)), "DDH.local_solution")
+        N.check_capi(lib.cuddh_ddh_local_solution(self._h, d0, d1, _ptr(lam, self.trace_dtype, self.size(), "lambda"), _ptr(f, "f64", 2 * self.fem.size(), "f"),
+                                                   _ptr(u, "f64", 2 * self.fem.size(), "u"), int(zero_u)), "DDH.local_solution")
 
 
 def gmres(n: int, x, A, b, m: int, maxit: int, tol: float = 1e-6, verbose: int = 0, max_seconds: float = 6 * 60 * 60, Precond=None,
@@ -453,9 +467,9 @@ def gmres(n: int, x, A, b, m: int, maxit: int, tol: float = 1e-6, verbose: int =
     h_res = np.zeros(maxit + 2)
     h_time = np.zeros(maxit + 2)
     if isinstance(A, DDH):
-        N.check_capi(lib.cuddh_gmres_ddh(n, _ptr(x), A._h, _ptr(b), m, maxit, float(tol), verbose, float(max_seconds), C.byref(res), _h(h_res), _h(h_time)), "gmres")
+        N.check_capi(lib.cuddh_gmres_ddh(n, _ptr(x, A.trace_dtype, n, "x"), A._h, _ptr(b, A.trace_dtype, n, "b"), m, maxit, float(tol), verbose, float(max_seconds), C.byref(res), _h(h_res), _h(h_time)), "gmres")
     elif isinstance(A, _Operator):
-        N.check_capi(lib.cuddh_gmres_f64(n, _ptr(x), A._h, _ptr(b), Precond._h if Precond is not None else None, m, maxit, float(tol), verbose,
+        N.check_capi(lib.cuddh_gmres_f64(n, _ptr(x, "f64", n, "x"), A._h, _ptr(b, "f64", n, "b"), Precond._h if Precond is not None else None, m, maxit, float(tol), verbose,
                                          float(max_seconds), C.byref(res), _h(h_res), _h(h_time)), "gmres")
     else:
         dtype = x.dtype
@@ -487,11 +501,11 @@ def gmres(n: int, x, A, b, m: int, maxit: int, tol: float = 1e-6, verbose: int =
 
         cfun = N.ACTION_CB(cb)
         if reduce is None:
-            N.check_capi(lib.cuddh_gmres_callback(n, _ptr(x), cfun, None, _ptr(b), int(is64), m, maxit, float(tol), verbose,
+            N.check_capi(lib.cuddh_gmres_callback(n, _ptr(x, dtype, n, "x"), cfun, None, _ptr(b, dtype, n, "b"), int(is64), m, maxit, float(tol), verbose,
                                                   float(max_seconds), C.byref(res), _h(h_res), _h(h_time)), "gmres")
         else:
             rfun = N.REDUCE_CB(red)
-            N.check_capi(lib.cuddh_gmres_callback_sharded(n, _ptr(x), cfun, None, rfun, None, _ptr(b), int(is64), m, maxit, float(tol),
+            N.check_capi(lib.cuddh_gmres_callback_sharded(n, _ptr(x, dtype, n, "x"), cfun, None, rfun, None, _ptr(b, dtype, n, "b"), int(is64), m, maxit, float(tol),
                                                           verbose, float(max_seconds), C.byref(res), _h(h_res), _h(h_time)), "gmres")
         if errors:
             raise errors[0]

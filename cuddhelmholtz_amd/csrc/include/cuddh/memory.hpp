@@ -15,6 +15,12 @@
 
 namespace cuddh
 {
+    /// the stream the library launches on (set_stream, launch.hpp), as the C ABI takes it
+    void *launch_stream();
+}
+
+namespace cuddh
+{
     enum class MemorySpace
     {
         HOST,
@@ -68,7 +74,7 @@ namespace cuddh
                 if (dev_fresh)
                 {
                     log("D -> H copy");
-                    detail::check_hip(cuddh_hip_copy_d2h(host, dev, bytes()), "HostDeviceArray device-to-host copy");
+                    detail::check_hip(cuddh_hip_copy_d2h_on(host, dev, bytes(), launch_stream()), "HostDeviceArray device-to-host copy");
                 }
             }
             host_fresh = true;
@@ -104,7 +110,7 @@ namespace cuddh
                 if (host_fresh)
                 {
                     log("H -> D copy");
-                    detail::check_hip(cuddh_hip_copy_h2d(dev, host, bytes()), "HostDeviceArray host-to-device copy");
+                    detail::check_hip(cuddh_hip_copy_h2d_on(dev, host, bytes(), launch_stream()), "HostDeviceArray host-to-device copy");
                 }
             }
             dev_fresh = true;

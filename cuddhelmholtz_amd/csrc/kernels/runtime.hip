@@ -11,7 +11,11 @@ extern "C"
         hipError_t e = hipMalloc(ptr, bytes);
         if (e != hipSuccess)
             return static_cast<int>(e);
-        e = hipMemset(*ptr, 0, bytes);
+        // the fill is complete when this returns: whatever stream touches the buffer next (the library's launch stream may be
+        // a non-blocking one, which the null stream does not order against) sees zeros
+        e = hipMemsetAsync(*ptr, 0, bytes, nullptr);
+        if (e == hipSuccess)
+            e = hipStreamSynchronize(nullptr);
         return static_cast<int>(e);
     }
 
@@ -25,6 +29,30 @@ extern "C"
     int cuddh_hip_copy_d2h(void *h_dst, const void *src, size_t bytes)
     {
         return bytes ? static_cast<int>(hipMemcpy(h_dst, src, bytes, hipMemcpyDeviceToHost)) : 0;
+    }
+
+    // Stream-ordered mirrors: the copy is queued behind the work already on `stream` (a blocking hipMemcpy on the null stream
+    // is NOT ordered against a non-blocking stream) and complete when the call returns.
+    int cuddh_hip_copy_h2d_on(void *dst, const void *h_src, size_t bytes, void *stream)
+    {
+        if (!bytes)
+            return 0;
+        hipStream_t st = cuddh_k::as_stream(stream);
+        hipError_t e = hipMemcpyAsync(dst, h_src, bytes, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess)
+            e = hipStreamSynchronize(st);
+        return static_cast<int>(e);
+    }
+
+    int cuddh_hip_copy_d2h_on(void *h_dst, const void *src, size_t bytes, void *stream)
+    {
+        if (!bytes)
+            return 0;
+        hipStream_t st = cuddh_k::as_stream(stream);
+        hipError_t e = hipMemcpyAsync(h_dst, src, bytes, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess)
+            e = hipStreamSynchronize(st);
+        return static_cast<int>(e);
     }
 
     int cuddh_hip_copy_d2d(void *dst, const void *src, size_t bytes, void *stream)

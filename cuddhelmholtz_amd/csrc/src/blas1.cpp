@@ -36,7 +36,7 @@ namespace cuddh
         {
             detail::check_hip(cuddh_hip_stream_sync(stream()), "stream sync");
             T v;
-            detail::check_hip(cuddh_hip_copy_d2h(&v, dev_scalar, sizeof(T)), "scalar copy");
+            detail::check_hip(cuddh_hip_copy_d2h_on(&v, dev_scalar, sizeof(T), stream()), "scalar copy");
             return v;
         }
     } // namespace

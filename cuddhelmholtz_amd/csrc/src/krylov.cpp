@@ -109,7 +109,7 @@ namespace cuddh
                 detail::check_hip(k_dot(n, v, v, dcol, ws), "gmres norm");
                 red->fn(red->user, dcol, 1, is_f64);
                 detail::check_hip(cuddh_hip_stream_sync(stream()), "gmres sync");
-                detail::check_hip(cuddh_hip_copy_d2h(&ss, dcol, sizeof(scalar)), "gmres norm copy");
+                detail::check_hip(cuddh_hip_copy_d2h_on(&ss, dcol, sizeof(scalar), stream()), "gmres norm copy");
                 return std::sqrt(ss);
             };
 
@@ -195,7 +195,7 @@ namespace cuddh
 
                     scalar *h = H.data() + static_cast<std::size_t>(m1) * k;
                     detail::check_hip(cuddh_hip_stream_sync(stream()), "gmres sync");
-                    detail::check_hip(cuddh_hip_copy_d2h(h, dcol, sizeof(scalar) * (k1 + 1)), "gmres column copy");
+                    detail::check_hip(cuddh_hip_copy_d2h_on(h, dcol, sizeof(scalar) * (k1 + 1), stream()), "gmres column copy");
                     if (red)
                     {
                         h[k1] = std::sqrt(h[k1]); // the reduced sum of squares

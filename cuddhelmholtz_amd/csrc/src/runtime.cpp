@@ -10,11 +10,14 @@ namespace cuddh
 {
     namespace
     {
-        hipStream_t g_stream = nullptr;
+        // per host thread: a thread that never calls set_stream launches on the null stream, and two threads driving the
+        // library on their own streams do not race on this variable (the reference has a single global stream: the null one)
+        thread_local hipStream_t g_stream = nullptr;
     }
 
     hipStream_t stream() { return g_stream; }
     void set_stream(hipStream_t s) { g_stream = s; }
+    void *launch_stream() { return g_stream; }
 
     namespace detail
     {

@@ -31,6 +31,10 @@ int cuddh_hip_malloc_zeroed(void **ptr, size_t bytes);
 int cuddh_hip_free(void *ptr);
 int cuddh_hip_copy_h2d(void *dst, const void *h_src, size_t bytes);
 int cuddh_hip_copy_d2h(void *h_dst, const void *src, size_t bytes);
+/* the same, queued on `stream` behind the work already there and complete on return (what HostDeviceArray mirrors and the
+ * solver's per-step coefficient copies use: the launch stream may be a non-blocking one) */
+int cuddh_hip_copy_h2d_on(void *dst, const void *h_src, size_t bytes, void *stream);
+int cuddh_hip_copy_d2h_on(void *h_dst, const void *src, size_t bytes, void *stream);
 int cuddh_hip_copy_d2d(void *dst, const void *src, size_t bytes, void *stream);
 /* include/linalg.hpp:46-48 (zeros -> cudaMemset) */
 int cuddh_hip_memset_zero(void *ptr, size_t bytes, void *stream);

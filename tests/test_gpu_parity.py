@@ -84,6 +84,37 @@ def test_blas1(cuda, dtype, n):
         assert float(yb[n - off if off == 0 else 0]) == 0.0
 
 
+def test_python_boundary_rejects_wrong_dtype_and_short_tensors(cuda):
+    """A float32 or too-short tensor handed to an fp64 entry point must be a Python error, not an out-of-bounds device access
+    behind the C ABI."""
+    import torch
+
+    import cuddhelmholtz_amd as cd
+
+    nx, nb = 8, 4
+    fem = cd.H1Space(cd.Mesh2D.uniform_rect(nx, -1.0, 1.0, nx, -1.0, 1.0), cd.Basis(nb))
+    n = fem.size()
+    S = cd.StiffnessMatrix(fem)
+    x64, y64 = torch.zeros(n, dtype=torch.float64, device=cuda), torch.zeros(n, dtype=torch.float64, device=cuda)
+    S.action(x64, y64)
+    with pytest.raises(ValueError, match="dtype"):
+        S.action(x64.float(), y64)
+    with pytest.raises(ValueError, match="at least"):
+        S.action(x64[: n - 1], y64)
+    with pytest.raises(ValueError, match="CUDA"):
+        S.action(x64.cpu(), y64)
+    F = cd.DDH(5.0, np.ones(n), fem, nx, nx)
+    f = torch.zeros(2 * n, dtype=torch.float64, device=cuda)
+    b = torch.zeros(F.size(), dtype=torch.float32, device=cuda)
+    F.rhs(f, b)
+    with pytest.raises(ValueError, match="dtype"):
+        F.rhs(f, b.double())  # fp32 DDH: traces are float
+    with pytest.raises(ValueError, match="at least"):
+        F.rhs(f[:n], b)
+    with pytest.raises(ValueError, match="dtype"):
+        cd.gmres(F.size(), b.double(), F, b, 5, 2, 1e-3)
+
+
 # ------------------------------------------------------------------ operators vs oracle
 @pytest.mark.parametrize("kind", ["structured", "unstructured"])
 @pytest.mark.parametrize("nb", [2, 3, 4, 5, 6, 7, 8])
