@@ -110,6 +110,10 @@ _sig("cuddh_hip_diag_scale_f64", ci, ci, ci, cd, vp, vp, vp, vp)
 _sig("cuddh_hip_reciprocal_f64", ci, ci, vp, vp)
 _sig("cuddh_hip_gather_f64", ci, ci, vp, vp, vp, vp)
 _sig("cuddh_hip_scatter_add_f64", ci, ci, vp, vp, vp, vp)
+_sig("cuddh_hip_trace_pack_f32", ci, ci, ci, vp, vp, vp, ci, vp)
+_sig("cuddh_hip_trace_pack_f64", ci, ci, ci, vp, vp, vp, ci, vp)
+_sig("cuddh_hip_trace_unpack_f32", ci, ci, ci, vp, vp, vp, vp)
+_sig("cuddh_hip_trace_unpack_f64", ci, ci, ci, vp, vp, vp, vp)
 _sig("cuddh_hip_zero_indexed_f64", ci, ci, vp, vp, vp)
 _sig("cuddh_hip_element_metrics", ci, ci, ci, vp, vp, vp, vp, vp, vp)
 _sig("cuddh_hip_stiffness_setup", ci, ci, ci, vp, vp, vp, vp)
@@ -197,6 +201,15 @@ _sig("cuddh_ddh_destroy", None, vp)
 _sig("cuddh_ddh_size", ci, vp)
 _sig("cuddh_ddh_info", ci, vp, vp, vp)
 _sig("cuddh_ddh_set_wh_iters", ci, vp, ci)
+
+
+class MultiGpuResult(C.Structure):
+    _fields_ = [("success", ci), ("num_iter", ci), ("num_matvec", ci), ("n_res", ci), ("world", ci), ("used_rccl", ci),
+                ("t_setup", cd), ("t_rhs", cd), ("t_gmres", cd), ("t_postprocess", cd), ("bytes_sent_per_action_rank0", C.c_longlong)]
+
+
+_sig("cuddh_ddh_solve_multi_gpu", ci, ci, ci, cd, vp, vp, vp, ci, ci, ci, cd, ci, C.POINTER(MultiGpuResult), vp)
+_sig("cuddh_trace_exchange_query", ci, vp, ci, ci, ci, ci, ci, ci, ci, vp)
 _sig("cuddh_ddh_rhs", ci, vp, vp, vp)
 _sig("cuddh_ddh_postprocess", ci, vp, vp, vp, vp)
 _sig("cuddh_ddh_action", ci, vp, vp, vp)

@@ -84,7 +84,8 @@ def build_native(verbose: bool = False, jobs: int = 6) -> Path:
         objs = list(pool.map(lambda sw: _compile(sw[0], sw[1], headers_mtime, verbose), work))
     newest = max(o.stat().st_mtime for o in objs)
     if not LIB_PATH.exists() or LIB_PATH.stat().st_mtime < newest:
-        cmd = [hipcc(), "-shared", f"--offload-arch={ARCH}", "-o", str(LIB_PATH), *map(str, objs)]
+        # (RCCL is bound at run time by csrc/src/multigpu.cpp, not linked: a host process may hold its own copy)
+        cmd = [hipcc(), "-shared", f"--offload-arch={ARCH}", "-o", str(LIB_PATH), *map(str, objs), "-ldl"]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)

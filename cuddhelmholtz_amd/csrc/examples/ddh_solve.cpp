@@ -1,10 +1,13 @@
 // Native C++ driver for the DDH path, written against csrc/include/cuddh.hpp (the same API the reference's
 // examples/DDH.cpp uses), with a command line instead of compile-time constants:
-//   ddh_solve [nx=128] [n_basis=4] [omega_over_pi=25.6] [gmres_m=20] [maxit=100] [tol=1e-4] [out_dir=solution]
+//   ddh_solve [nx=128] [n_basis=4] [omega_over_pi=25.6] [gmres_m=20] [maxit=100] [tol=1e-4] [out_dir=solution] [devices=0] [force_rccl=0]
 // Writes <out_dir>/xy.0000 and <out_dir>/ddh.0000 (raw fp64, like the reference) and prints one summary line.
+// devices >= 1: the same solve through cuddh::ddh_solve_multi_gpu (multigpu.hpp): subdomains sharded over that many GPUs of
+// this process, RCCL neighbour exchange; devices = 1 with force_rccl = 1 runs the communicator path on a one-GPU box.
 #include <chrono>
 #include <cstdlib>
 #include <string>
+#include <vector>
 
 #include "cuddh.hpp"
 #include "cuddh_hip.h"
@@ -21,6 +24,8 @@ int main(int argc, char **argv)
     const int maxit = argc > 5 ? std::atoi(argv[5]) : 100;
     const float tol = argc > 6 ? static_cast<float>(std::atof(argv[6])) : 1e-4f;
     const std::string out_dir = argc > 7 ? argv[7] : "solution";
+    const int devices = argc > 8 ? std::atoi(argv[8]) : 0;
+    const bool force_rccl = argc > 9 && std::atoi(argv[9]) != 0;
 
     Mesh2D mesh = Mesh2D::uniform_rect(nx, -1.0, 1.0, nx, -1.0, 1.0);
     Basis basis(nb);
@@ -41,6 +46,27 @@ int main(int argc, char **argv)
     }, d_b);
     l.action([] __device__(const double X[2]) -> double { return (X[0] * X[0] + X[1] * X[1] < 0.0625) ? 0.2 : 1.0; }, d_a);
     mi.action(d_a, d_a);
+
+    if (devices >= 1)
+    {
+        std::vector<double> h_u(N);
+        const multi_gpu_result r = ddh_solve_multi_gpu(nx, nb, omega, a.host_read(), b.host_read(), h_u.data(), devices, m, maxit, tol, force_rccl);
+        if (out_dir != "-")
+        {
+            to_file(out_dir + "/xy.0000", N, fem.physical_coordinates(MemorySpace::HOST));
+            to_file(out_dir + "/ddh.0000", N, h_u.data());
+        }
+        double unorm = 0.0;
+        for (int i = 0; i < N; ++i)
+            unorm += h_u[i] * h_u[i];
+        std::cout << "ddh_solve nx=" << nx << " nb=" << nb << " omega/pi=" << omega / M_PI << " ndof=" << ndof << " devices=" << r.world
+                  << " rccl=" << r.used_rccl << " success=" << r.gmres.success << " num_iter=" << r.gmres.num_iter
+                  << " num_matvec=" << r.gmres.num_matvec << " rel_res=" << r.gmres.res_norm.back() / r.gmres.res_norm.front()
+                  << " |u|=" << std::sqrt(unorm) << " t_setup=" << r.t_setup << " t_rhs=" << r.t_rhs << " t_gmres=" << r.t_gmres
+                  << " t_postprocess=" << r.t_postprocess << " sent_bytes_per_action_rank0=" << r.bytes_sent_per_action_rank0
+                  << " DoF*iter/s=" << 2.0 * ndof * r.gmres.num_matvec / r.t_gmres << std::endl;
+        return 0;
+    }
 
     DDH F(omega, a.host_read(), fem, nx, nx);
     const int n_lambda = F.size();

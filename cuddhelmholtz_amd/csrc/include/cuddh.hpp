@@ -24,5 +24,6 @@
 #include "cuddh/krylov.hpp"
 #include "cuddh/ddh.hpp"
 #include "cuddh/helmholtz.hpp"
+#include "cuddh/multigpu.hpp"
 
 #endif

@@ -1,0 +1,58 @@
+// DDH over the GPUs of one node from ONE process: the subdomain range is cut into `world` contiguous pieces,
+// one per device; every device runs its piece of the local solves on its own stream, the traces its subdomains write for
+// subdomains of another piece travel by one grouped RCCL send/recv per action (ncclGroupStart / ncclSend / ncclRecv /
+// ncclGroupEnd over xGMI -- the neighbour all-to-all of the north star), and GMRES runs on partitioned trace vectors with
+// every inner product summed by ncclAllReduce through the ScalarReduce hook of krylov.hpp, so all devices take identical
+// decisions.  The reference is single-GPU; this layer is new.  The Python host (cuddhelmholtz_amd/dist.py, one process per
+// GPU over torch.distributed) implements the same scheme; TraceExchangePlan here and TraceExchange there produce identical
+// ownership / send / receive lists (tests/test_distributed_gloo.py).
+#ifndef CUDDH_AMD_MULTIGPU_HPP
+#define CUDDH_AMD_MULTIGPU_HPP
+
+#include <map>
+#include <memory>
+#include <vector>
+
+#include "krylov.hpp"
+
+namespace cuddh
+{
+    /// contiguous balanced range of n_items for `rank` of `world`
+    inline void shard_range(int n_items, int rank, int world, int &begin, int &end)
+    {
+        begin = static_cast<int>((static_cast<long long>(n_items) * rank) / world);
+        end = static_cast<int>((static_cast<long long>(n_items) * (rank + 1)) / world);
+    }
+
+    /// Who owns, sends and receives which trace slots, from the slot table B (mx_fdof, 2, n_domains) of the DDH constructor
+    /// (reference source/DDH.cpp:425-440: B(i,0,S) is the slot subdomain S reads for its face dof i, B(i,1,S) the slot it
+    /// writes).  owner(slot) = rank of the subdomain that reads it, else of the one that writes it; slots nobody touches
+    /// (the reference's orphan slots at cross points) belong to nobody and stay zero.  Host-only.
+    struct TraceExchangePlan
+    {
+        int rank = 0, world = 1, n_lambda = 0, dom_begin = 0, dom_end = 0;
+        std::vector<int> owned;                // slots this rank owns, increasing
+        std::map<int, std::vector<int>> send;  // peer -> slots this rank's subdomains write and the peer owns, increasing
+        std::map<int, std::vector<int>> recv;  // peer -> slots this rank owns and the peer's subdomains write, increasing
+
+        static TraceExchangePlan build(const int *B, int n_domains, int mx_fdof, int n_lambda, int rank, int world);
+    };
+
+    struct multi_gpu_result
+    {
+        solver_out gmres;
+        double t_setup = 0, t_rhs = 0, t_gmres = 0, t_postprocess = 0; // seconds, max over ranks
+        int world = 1;
+        bool used_rccl = false;
+        long long bytes_sent_per_action_rank0 = 0;
+    };
+
+    /// The flow of examples/DDH.cpp:141-144 (rhs -> gmres -> postprocess) on `world` devices of this process: uniform_rect
+    /// (nx x nx on [-1,1]^2), Basis(nb), h_a nodal coefficient (HOST, global numbering), h_f = [f; g] load vector (HOST,
+    /// 2 ndof), h_u receives [u; v] (HOST, 2 ndof).  world = 1 runs without communicator unless force_rccl is set (then the
+    /// one-rank communicator carries the reductions: exercises the RCCL path on a one-GPU box).
+    multi_gpu_result ddh_solve_multi_gpu(int nx, int nb, double omega, const double *h_a, const double *h_f, double *h_u, int world,
+                                         int gmres_m, int gmres_maxit, float tol, bool force_rccl = false);
+} // namespace cuddh
+
+#endif

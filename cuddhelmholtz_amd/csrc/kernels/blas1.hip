@@ -427,6 +427,36 @@ namespace
             x[proj[i]] = 0.0;
     }
 
+    // trace exchange of the multi-GPU DDH path (slot t stands for entries t and n_half + t of a trace vector):
+    // pack: buf[i] = v[slot[i]], buf[n + i] = v[n_half + slot[i]] and, with clear != 0, v <- 0 there (the slots belong to the
+    // receiving rank); unpack: v[slot[i]] = buf[i], v[n_half + slot[i]] = buf[n + i]
+    template <typename T>
+    __global__ void __launch_bounds__(BLOCK) trace_pack_kernel(int n, int n_half, const int *__restrict__ slot, T *__restrict__ v, T *__restrict__ buf, int clear)
+    {
+        for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK)
+        {
+            const int t = slot[i];
+            buf[i] = v[t];
+            buf[n + i] = v[n_half + t];
+            if (clear)
+            {
+                v[t] = T(0);
+                v[n_half + t] = T(0);
+            }
+        }
+    }
+
+    template <typename T>
+    __global__ void __launch_bounds__(BLOCK) trace_unpack_kernel(int n, int n_half, const int *__restrict__ slot, const T *__restrict__ buf, T *__restrict__ v)
+    {
+        for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK)
+        {
+            const int t = slot[i];
+            v[t] = buf[i];
+            v[n_half + t] = buf[n + i];
+        }
+    }
+
     __global__ void __launch_bounds__(BLOCK) diag_scale_kernel(int n, int accumulate, double c, const double *__restrict__ p, const double *x, double *y)
     {
         // x may alias y (DiagInvMassMatrix is applied in place by the DDH example)
@@ -523,6 +553,30 @@ extern "C"
             return 0;
         hipLaunchKernelGGL(scatter_add_kernel, dim3(stream_grid(n, BLOCK)), dim3(BLOCK), 0, as_stream(s), n, proj, x, y);
         return launch_status();
+    }
+    int cuddh_hip_trace_pack_f32(int n, int n_half, const int *slot, float *v, float *buf, int clear, void *s)
+    {
+        if (n > 0)
+            hipLaunchKernelGGL((trace_pack_kernel<float>), dim3(stream_grid(n, BLOCK)), dim3(BLOCK), 0, as_stream(s), n, n_half, slot, v, buf, clear);
+        return n > 0 ? launch_status() : 0;
+    }
+    int cuddh_hip_trace_pack_f64(int n, int n_half, const int *slot, double *v, double *buf, int clear, void *s)
+    {
+        if (n > 0)
+            hipLaunchKernelGGL((trace_pack_kernel<double>), dim3(stream_grid(n, BLOCK)), dim3(BLOCK), 0, as_stream(s), n, n_half, slot, v, buf, clear);
+        return n > 0 ? launch_status() : 0;
+    }
+    int cuddh_hip_trace_unpack_f32(int n, int n_half, const int *slot, const float *buf, float *v, void *s)
+    {
+        if (n > 0)
+            hipLaunchKernelGGL((trace_unpack_kernel<float>), dim3(stream_grid(n, BLOCK)), dim3(BLOCK), 0, as_stream(s), n, n_half, slot, buf, v);
+        return n > 0 ? launch_status() : 0;
+    }
+    int cuddh_hip_trace_unpack_f64(int n, int n_half, const int *slot, const double *buf, double *v, void *s)
+    {
+        if (n > 0)
+            hipLaunchKernelGGL((trace_unpack_kernel<double>), dim3(stream_grid(n, BLOCK)), dim3(BLOCK), 0, as_stream(s), n, n_half, slot, buf, v);
+        return n > 0 ? launch_status() : 0;
     }
     int cuddh_hip_zero_indexed_f64(int n, const int *proj, double *x, void *s)
     {

@@ -613,6 +613,50 @@ extern "C"
             info[7] = h->is64() ? 1 : 0;
         });
     }
+    int cuddh_ddh_solve_multi_gpu(int nx, int nb, double omega, const double *h_a, const double *h_f, double *h_u, int world, int m,
+                                  int maxit, double tol, int force_rccl, cuddh_multi_gpu_result *out, double *h_res)
+    {
+        return guarded([&]
+        {
+            const multi_gpu_result r = ddh_solve_multi_gpu(nx, nb, omega, h_a, h_f, h_u, world, m, maxit, static_cast<float>(tol), force_rccl != 0);
+            out->success = r.gmres.success ? 1 : 0;
+            out->num_iter = r.gmres.num_iter;
+            out->num_matvec = r.gmres.num_matvec;
+            out->n_res = static_cast<int>(r.gmres.res_norm.size());
+            out->world = r.world;
+            out->used_rccl = r.used_rccl ? 1 : 0;
+            out->t_setup = r.t_setup;
+            out->t_rhs = r.t_rhs;
+            out->t_gmres = r.t_gmres;
+            out->t_postprocess = r.t_postprocess;
+            out->bytes_sent_per_action_rank0 = r.bytes_sent_per_action_rank0;
+            for (int i = 0; i < out->n_res && i < maxit + 2; ++i)
+                h_res[i] = r.gmres.res_norm[i];
+        });
+    }
+    int cuddh_trace_exchange_query(const int *h_B, int n_domains, int mx_fdof, int n_lambda, int rank, int world, int which, int peer,
+                                   int *h_out)
+    {
+        int count = -1;
+        const int err = guarded([&]
+        {
+            const TraceExchangePlan p = TraceExchangePlan::build(h_B, n_domains, mx_fdof, n_lambda, rank, world);
+            const std::vector<int> *v = nullptr;
+            static const std::vector<int> none;
+            if (which == 0)
+                v = &p.owned;
+            else
+            {
+                const auto &m = which == 1 ? p.send : p.recv;
+                const auto it = m.find(peer);
+                v = it == m.end() ? &none : &it->second;
+            }
+            count = static_cast<int>(v->size());
+            if (h_out)
+                std::copy(v->begin(), v->end(), h_out);
+        });
+        return err ? -1 : count;
+    }
     int cuddh_ddh_set_wh_iters(void *d, int n)
     {
         return guarded([&]

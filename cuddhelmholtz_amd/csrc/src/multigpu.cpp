@@ -1,0 +1,349 @@
+// One process, `world` devices: DDH with subdomains sharded over the devices and RCCL neighbour exchange (multigpu.hpp).
+#include "cuddh/multigpu.hpp"
+
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h> // types and prototypes only: the library is bound at run time, see Rccl below
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstring>
+#include <exception>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <type_traits>
+
+#include "cuddh/basis.hpp"
+#include "cuddh/ddh.hpp"
+#include "cuddh/launch.hpp"
+#include "cuddh/mesh.hpp"
+#include "cuddh/spaces.hpp"
+#include "cuddh_hip.h"
+
+namespace cuddh
+{
+    TraceExchangePlan TraceExchangePlan::build(const int *B, int n_domains, int mx_fdof, int n_lambda, int rank, int world)
+    {
+        if (rank < 0 || rank >= world)
+            cuddh_error("TraceExchangePlan error: rank out of range.");
+        TraceExchangePlan p;
+        p.rank = rank;
+        p.world = world;
+        p.n_lambda = n_lambda;
+        shard_range(n_domains, rank, world, p.dom_begin, p.dom_end);
+
+        std::vector<int> dom_rank(n_domains);
+        for (int r = 0; r < world; ++r)
+        {
+            int a, b;
+            shard_range(n_domains, r, world, a, b);
+            std::fill(dom_rank.begin() + a, dom_rank.begin() + b, r);
+        }
+        std::vector<int> reader(n_lambda, -1), writer(n_lambda, -1);
+        for (int s = 0; s < n_domains; ++s)
+            for (int col = 0; col < 2; ++col)
+                for (int i = 0; i < mx_fdof; ++i)
+                {
+                    const int t = B[i + static_cast<std::size_t>(mx_fdof) * (col + 2 * static_cast<std::size_t>(s))];
+                    if (t < 0)
+                        continue;
+                    std::vector<int> &who = col == 0 ? reader : writer;
+                    if (t >= n_lambda || who[t] >= 0)
+                        cuddh_error("DDH slot table: a slot is used by two subdomains or is out of range");
+                    who[t] = s;
+                }
+        for (int t = 0; t < n_lambda; ++t)
+        {
+            const int owner_dom = reader[t] >= 0 ? reader[t] : writer[t];
+            const int owner = owner_dom >= 0 ? dom_rank[owner_dom] : -1;
+            const int wrank = writer[t] >= 0 ? dom_rank[writer[t]] : -1;
+            if (owner == rank)
+            {
+                p.owned.push_back(t);
+                if (wrank >= 0 && wrank != rank)
+                    p.recv[wrank].push_back(t);
+            }
+            else if (owner >= 0 && wrank == rank)
+                p.send[owner].push_back(t);
+        }
+        return p;
+    }
+
+    namespace
+    {
+        // RCCL is bound with dlopen at first use instead of being a link-time dependency: a host process may already hold a
+        // copy (PyTorch ships its own librccl.so), and two copies of the library in one process corrupt each other's state at
+        // exit.  dlopen by name returns the copy that is already loaded, if any; otherwise ROCm's.
+        struct Rccl
+        {
+            decltype(&ncclCommInitAll) CommInitAll = nullptr;
+            decltype(&ncclCommDestroy) CommDestroy = nullptr;
+            decltype(&ncclGroupStart) GroupStart = nullptr;
+            decltype(&ncclGroupEnd) GroupEnd = nullptr;
+            decltype(&ncclSend) Send = nullptr;
+            decltype(&ncclRecv) Recv = nullptr;
+            decltype(&ncclAllReduce) AllReduce = nullptr;
+            decltype(&ncclGetErrorString) GetErrorString = nullptr;
+
+            static const Rccl &get()
+            {
+                static const Rccl api = load();
+                return api;
+            }
+
+        private:
+            static Rccl load()
+            {
+                void *h = nullptr;
+                for (const char *name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"})
+                {
+                    h = dlopen(name, RTLD_NOW | RTLD_NOLOAD); // a copy the process already holds
+                    if (h)
+                        break;
+                }
+                if (!h)
+                    for (const char *name : {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"})
+                    {
+                        h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+                        if (h)
+                            break;
+                    }
+                if (!h)
+                    throw std::runtime_error(std::string("RCCL is not available: ") + dlerror());
+                Rccl a;
+                auto bind = [&](auto &fn, const char *sym)
+                {
+                    fn = reinterpret_cast<std::remove_reference_t<decltype(fn)>>(dlsym(h, sym));
+                    if (!fn)
+                        throw std::runtime_error(std::string("RCCL symbol missing: ") + sym);
+                };
+                bind(a.CommInitAll, "ncclCommInitAll");
+                bind(a.CommDestroy, "ncclCommDestroy");
+                bind(a.GroupStart, "ncclGroupStart");
+                bind(a.GroupEnd, "ncclGroupEnd");
+                bind(a.Send, "ncclSend");
+                bind(a.Recv, "ncclRecv");
+                bind(a.AllReduce, "ncclAllReduce");
+                bind(a.GetErrorString, "ncclGetErrorString");
+                return a;
+            }
+        };
+
+        void check_nccl(ncclResult_t r, const char *what)
+        {
+            if (r != ncclSuccess)
+                throw std::runtime_error(std::string(what) + ": " + Rccl::get().GetErrorString(r));
+        }
+
+        using clk = std::chrono::steady_clock;
+        double since(clk::time_point t) { return std::chrono::duration<double>(clk::now() - t).count(); }
+
+        // everything one device needs, built and used by that device's host thread only
+        struct Rank
+        {
+            int rank, world, device;
+            ncclComm_t comm = nullptr; // null: no communicator (world == 1 without force_rccl)
+            hipStream_t st = nullptr;
+            std::unique_ptr<Mesh2D> mesh;
+            std::unique_ptr<Basis> basis;
+            std::unique_ptr<H1Space> fem;
+            std::unique_ptr<DDH> F;
+            TraceExchangePlan plan;
+            std::map<int, HostDeviceArray<int>> send_slots, recv_slots;
+            std::map<int, HostDeviceArray<float>> sbuf, rbuf;
+
+            void sync() const { detail::check_hip(cuddh_hip_stream_sync(st), "stream sync"); }
+
+            /// out <- traces written by this rank's subdomains into slots it owns + traces received from the other ranks
+            void traces(const double *f, const float *lambda, float *out)
+            {
+                const int n = F->size();
+                detail::check_hip(cuddh_hip_memset_zero(out, sizeof(float) * n, st), "trace zero fill");
+                F->local_traces(plan.dom_begin, plan.dom_end, f, lambda, out);
+                if (world == 1)
+                    return;
+                const int n_half = n / 2; // = 2 n_shared: lambda half and mu half of a trace vector
+                for (auto &kv : send_slots)
+                {
+                    const int cnt = kv.second.size();
+                    detail::check_hip(cuddh_hip_trace_pack_f32(cnt, n_half, kv.second.device_read(), out, sbuf[kv.first].device_write(), 1, st),
+                                      "trace pack");
+                }
+                check_nccl(Rccl::get().GroupStart(), "ncclGroupStart");
+                for (int peer = 0; peer < world; ++peer)
+                {
+                    auto s = send_slots.find(peer);
+                    if (s != send_slots.end())
+                        check_nccl(Rccl::get().Send(sbuf[peer].device_read(), 2 * static_cast<size_t>(s->second.size()), ncclFloat, peer, comm, st), "ncclSend");
+                    auto r = recv_slots.find(peer);
+                    if (r != recv_slots.end())
+                        check_nccl(Rccl::get().Recv(rbuf[peer].device_write(), 2 * static_cast<size_t>(r->second.size()), ncclFloat, peer, comm, st), "ncclRecv");
+                }
+                check_nccl(Rccl::get().GroupEnd(), "ncclGroupEnd");
+                for (auto &kv : recv_slots)
+                    detail::check_hip(cuddh_hip_trace_unpack_f32(kv.second.size(), n_half, kv.second.device_read(), rbuf[kv.first].device_read(), out, st),
+                                      "trace unpack");
+            }
+
+            void all_reduce(void *d, size_t count, ncclDataType_t type) const
+            {
+                if (comm)
+                    check_nccl(Rccl::get().AllReduce(d, d, count, type, ncclSum, comm, st), "ncclAllReduce");
+            }
+        };
+
+        // (I - T) on the partitioned trace vectors of one rank
+        class ShardOperator : public SinglePrecisionOperator
+        {
+        public:
+            explicit ShardOperator(Rank &r_) : r(r_) {}
+            void action(const float *x, float *y) const override
+            {
+                r.traces(nullptr, x, y);
+                axpby(r.F->size(), 1.0f, x, -1.0f, y);
+            }
+
+        private:
+            Rank &r;
+        };
+
+        void reduce_hook(void *user, void *d_scalars, int count, int is_f64)
+        {
+            static_cast<Rank *>(user)->all_reduce(d_scalars, static_cast<size_t>(count), is_f64 ? ncclDouble : ncclFloat);
+        }
+    } // namespace
+
+    multi_gpu_result ddh_solve_multi_gpu(int nx, int nb, double omega, const double *h_a, const double *h_f, double *h_u, int world,
+                                         int gmres_m, int gmres_maxit, float tol, bool force_rccl)
+    {
+        int n_dev = 0;
+        detail::check_hip(static_cast<int>(hipGetDeviceCount(&n_dev)), "hipGetDeviceCount");
+        if (world < 1 || world > n_dev)
+            cuddh_error("ddh_solve_multi_gpu error: need 1 <= world <= number of visible devices (one rank per GPU).");
+        const bool use_rccl = world > 1 || force_rccl;
+
+        std::vector<ncclComm_t> comms(world, nullptr);
+        if (use_rccl)
+        {
+            std::vector<int> devs(world);
+            for (int r = 0; r < world; ++r)
+                devs[r] = r;
+            check_nccl(Rccl::get().CommInitAll(comms.data(), world, devs.data()), "ncclCommInitAll");
+        }
+
+        multi_gpu_result res;
+        res.world = world;
+        res.used_rccl = use_rccl;
+        std::vector<double> t_setup(world, 0), t_rhs(world, 0), t_gmres(world, 0), t_post(world, 0);
+        std::vector<solver_out> outs(world);
+        std::vector<std::exception_ptr> errors(world);
+        std::mutex host_out; // h_u is written by rank 0 only; the mutex guards nothing else
+
+        auto body = [&](int rank)
+        {
+            try
+            {
+                detail::check_hip(static_cast<int>(hipSetDevice(rank)), "hipSetDevice");
+                Rank R;
+                R.rank = rank;
+                R.world = world;
+                R.device = rank;
+                R.comm = comms[rank];
+                detail::check_hip(static_cast<int>(hipStreamCreateWithFlags(&R.st, hipStreamNonBlocking)), "hipStreamCreate");
+                set_stream(R.st); // thread-local: this thread's launches go to this device's stream
+
+                auto t0 = clk::now();
+                R.mesh.reset(new Mesh2D(Mesh2D::uniform_rect(nx, -1.0, 1.0, nx, -1.0, 1.0)));
+                R.basis.reset(new Basis(nb));
+                R.fem.reset(new H1Space(*R.mesh, *R.basis));
+                const int ndof = R.fem->size();
+                R.F.reset(new DDH(omega, h_a, *R.fem, nx, nx));
+                const auto &core = R.F->internals();
+                const int n = R.F->size();
+                R.plan = TraceExchangePlan::build(core.table_B().host_read(), core.num_domains(), core.max_fdof(), n / 2, rank, world);
+                auto upload = [](const std::vector<int> &v, HostDeviceArray<int> &dst)
+                {
+                    dst.resize(static_cast<int>(v.size()));
+                    std::copy(v.begin(), v.end(), dst.host_write());
+                };
+                for (const auto &kv : R.plan.send)
+                {
+                    upload(kv.second, R.send_slots[kv.first]);
+                    R.sbuf[kv.first].resize(2 * static_cast<int>(kv.second.size()));
+                }
+                for (const auto &kv : R.plan.recv)
+                {
+                    upload(kv.second, R.recv_slots[kv.first]);
+                    R.rbuf[kv.first].resize(2 * static_cast<int>(kv.second.size()));
+                }
+                if (rank == 0)
+                    for (const auto &kv : R.plan.send)
+                        res.bytes_sent_per_action_rank0 += 2LL * kv.second.size() * sizeof(float);
+
+                host_device_dvec f(2 * ndof), u(2 * ndof);
+                std::memcpy(f.host_write(), h_f, sizeof(double) * 2 * ndof);
+                const double *d_f = f.device_read();
+                HostDeviceArray<float> b(n), lam(n);
+                float *d_b = b.device_write(), *d_lam = lam.device_write();
+                R.sync();
+                t_setup[rank] = since(t0);
+
+                t0 = clk::now();
+                R.traces(d_f, nullptr, d_b); // DDH::rhs on the partitioned vectors
+                R.sync();
+                t_rhs[rank] = since(t0);
+
+                ShardOperator A(R);
+                const ScalarReduce red{reduce_hook, &R};
+                t0 = clk::now();
+                outs[rank] = use_rccl ? gmres(n, d_lam, &A, d_b, gmres_m, gmres_maxit, tol, 0, 6 * 60 * 60.0, red)
+                                      : gmres(n, d_lam, &A, d_b, gmres_m, gmres_maxit, tol, 0);
+                R.sync();
+                t_gmres[rank] = since(t0);
+
+                t0 = clk::now();
+                double *d_u = u.device_write();
+                R.F->local_solution(R.plan.dom_begin, R.plan.dom_end, d_lam, d_f, d_u, true);
+                R.all_reduce(d_u, 2 * static_cast<size_t>(ndof), ncclDouble); // partition-of-unity sums cross the pieces
+                R.sync();
+                t_post[rank] = since(t0);
+                if (rank == 0)
+                {
+                    std::lock_guard<std::mutex> lock(host_out);
+                    std::memcpy(h_u, u.host_read(), sizeof(double) * 2 * ndof);
+                }
+                R.F.reset();
+                R.fem.reset();
+                set_stream(nullptr);
+                (void)hipStreamDestroy(R.st);
+            }
+            catch (...)
+            {
+                errors[rank] = std::current_exception();
+            }
+        };
+
+        std::vector<std::thread> threads;
+        for (int r = 1; r < world; ++r)
+            threads.emplace_back(body, r);
+        body(0);
+        for (auto &t : threads)
+            t.join();
+        for (auto &c : comms)
+            if (c)
+                (void)Rccl::get().CommDestroy(c);
+        (void)hipSetDevice(0);
+        for (const auto &e : errors)
+            if (e)
+                std::rethrow_exception(e);
+
+        res.gmres = outs[0];
+        res.t_setup = *std::max_element(t_setup.begin(), t_setup.end());
+        res.t_rhs = *std::max_element(t_rhs.begin(), t_rhs.end());
+        res.t_gmres = *std::max_element(t_gmres.begin(), t_gmres.end());
+        res.t_postprocess = *std::max_element(t_post.begin(), t_post.end());
+        return res;
+    }
+} // namespace cuddh

@@ -72,6 +72,56 @@ class ShardedDDH:
         self._all_reduce(u)
 
 
+def native_trace_exchange(B, n_domains: int, mx_fdof: int, n_lambda: int, rank: int, world: int):
+    """The ownership / send / receive slot lists as the C++ multi-GPU host computes them (cuddh::TraceExchangePlan,
+    csrc/src/multigpu.cpp): (owned, {peer: send slots}, {peer: recv slots}).  Must equal TraceExchange's."""
+    import ctypes as C
+
+    import numpy as np
+
+    from ._native import lib
+
+    B = np.ascontiguousarray(np.asarray(B, dtype=np.int32).reshape(-1))
+    pB = B.ctypes.data_as(C.c_void_p)
+
+    def query(which, peer):
+        n = lib.cuddh_trace_exchange_query(pB, n_domains, mx_fdof, n_lambda, rank, world, which, peer, None)
+        if n < 0:
+            raise RuntimeError("cuddh_trace_exchange_query failed")
+        out = np.empty(n, dtype=np.int32)
+        if n:
+            lib.cuddh_trace_exchange_query(pB, n_domains, mx_fdof, n_lambda, rank, world, which, peer, out.ctypes.data_as(C.c_void_p))
+        return out
+
+    owned = query(0, 0)
+    send = {p: a for p in range(world) if p != rank and (a := query(1, p)).size}
+    recv = {p: a for p in range(world) if p != rank and (a := query(2, p)).size}
+    return owned, send, recv
+
+
+def ddh_solve_multi_gpu(nx: int, nb: int, omega: float, h_a, h_f, world: int, m: int = 20, maxit: int = 100, tol: float = 1e-4,
+                        force_rccl: bool = False):
+    """rhs -> gmres -> postprocess on `world` GPUs of this process through the C++ host (cuddh::ddh_solve_multi_gpu: one
+    host thread per device, RCCL send/recv for the traces, ncclAllReduce for the inner products).  Host arrays in, (u, info) out."""
+    import ctypes as C
+
+    import numpy as np
+
+    from . import _native as N
+
+    h_a = np.ascontiguousarray(h_a, dtype=np.float64)
+    h_f = np.ascontiguousarray(h_f, dtype=np.float64)
+    u = np.zeros_like(h_f)
+    res = N.MultiGpuResult()
+    hist = np.zeros(maxit + 2)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    N.check_capi(N.lib.cuddh_ddh_solve_multi_gpu(nx, nb, float(omega), vp(h_a), vp(h_f), vp(u), world, m, maxit, float(tol), int(force_rccl),
+                                                C.byref(res), vp(hist)), "ddh_solve_multi_gpu")
+    info = {k: getattr(res, k) for k, _ in N.MultiGpuResult._fields_}
+    info["res_norm"] = hist[: res.n_res].tolist()
+    return u, info
+
+
 def _runs(ids):
     """sorted integer ids -> list of half-open (begin, end) runs"""
     out = []

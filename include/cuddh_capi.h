@@ -111,6 +111,22 @@ void cuddh_ddh_destroy(void *ddh);
 int cuddh_ddh_size(void *ddh);
 /* h_info = {n_domains, nt, n_lambda, mx_dof, mx_fdof, nel1d, kernel (needs a GPU; -1 if none), is_f64}; *h_dt = time step */
 int cuddh_ddh_info(void *ddh, int *h_info, double *h_dt);
+/* ---- DDH over the GPUs of one node from one process (csrc/include/cuddh/multigpu.hpp; RCCL send/recv + all-reduce) */
+typedef struct cuddh_multi_gpu_result
+{
+    int success, num_iter, num_matvec, n_res, world, used_rccl;
+    double t_setup, t_rhs, t_gmres, t_postprocess;
+    long long bytes_sent_per_action_rank0;
+} cuddh_multi_gpu_result;
+/* rhs -> gmres -> postprocess of examples/DDH.cpp:141-144 on uniform_rect(nx), Basis(nb), fp32 DDH, `world` devices.
+ * h_a (ndof), h_f (2 ndof), h_u (2 ndof) HOST in the global numbering; h_res (maxit + 2) receives the residual history. */
+int cuddh_ddh_solve_multi_gpu(int nx, int nb, double omega, const double *h_a, const double *h_f, double *h_u, int world, int m,
+                              int maxit, double tol, int force_rccl, cuddh_multi_gpu_result *out, double *h_res);
+/* ownership / send / receive lists of the trace exchange for `rank` of `world` (host only; what both the C++ and the
+ * Python multi-GPU hosts use).  which: 0 owned slots, 1 slots sent to `peer`, 2 slots received from `peer`.  Returns the
+ * count (-1 on error); h_out may be NULL to ask for the count only.  h_B: (mx_fdof, 2, n_domains). */
+int cuddh_trace_exchange_query(const int *h_B, int n_domains, int mx_fdof, int n_lambda, int rank, int world, int which, int peer,
+                               int *h_out);
 /* verification knob: WaveHoltz iterations per local solve (reference: 5, source/DDH.cpp:136; 0 restores it) */
 int cuddh_ddh_set_wh_iters(void *ddh, int n);
 /* traces are float for f64 == 0 and double otherwise */

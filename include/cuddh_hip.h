@@ -98,6 +98,13 @@ int cuddh_hip_reciprocal_f64(int n, double *x, void *stream);
 int cuddh_hip_gather_f64(int n, const int *proj, const double *x, double *y, void *stream);      /* y[i]  = x[proj[i]] */
 int cuddh_hip_scatter_add_f64(int n, const int *proj, const double *x, double *y, void *stream); /* y[proj[i]] += x[i] */
 int cuddh_hip_zero_indexed_f64(int n, const int *proj, double *x, void *stream);                 /* x[proj[i]] = 0 */
+/* Trace exchange of the multi-GPU DDH path (new: the reference is single-GPU).  A slot t stands for entries t and n_half + t
+ * of a trace vector v (lambda and mu halves).  pack: buf[i] = v[slot[i]], buf[n + i] = v[n_half + slot[i]] and, with
+ * clear != 0, those entries of v are zeroed (they belong to the receiving rank); unpack: the inverse copy. */
+int cuddh_hip_trace_pack_f32(int n, int n_half, const int *slot, float *v, float *buf, int clear, void *stream);
+int cuddh_hip_trace_pack_f64(int n, int n_half, const int *slot, double *v, double *buf, int clear, void *stream);
+int cuddh_hip_trace_unpack_f32(int n, int n_half, const int *slot, const float *buf, float *v, void *stream);
+int cuddh_hip_trace_unpack_f64(int n, int n_half, const int *slot, const double *buf, double *v, void *stream);
 
 /* ------------------------------------------------------------------ element operators (fp64)
  * Shapes: P,D (nq,nb); I (nb,nb,n_elem); J (2,2,nq,nq,n_elem); detJ (nq,nq,n_elem);

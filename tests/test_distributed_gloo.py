@@ -308,3 +308,25 @@ def test_helmholtz_partition_replay(kind, nb, unstructured_square):
             out[p.l2g[p.owned]] = y[p.owned]
             out[ndof + p.l2g[p.owned]] = y[p.n_loc + p.owned]
         assert np.linalg.norm(out - ref) <= 1e-13 * np.linalg.norm(ref)
+
+
+@pytest.mark.parametrize("nx,nb,world", [(16, 4, 2), (16, 4, 3), (32, 4, 8), (8, 8, 5), (10, 3, 4)])
+def test_native_trace_exchange_plan_equals_python(nx, nb, world):
+    """cuddh::TraceExchangePlan (the C++ multi-GPU host, csrc/src/multigpu.cpp) and dist.TraceExchange (the Python host)
+    derive ownership, send and receive lists from the same slot table: they must be identical, list by list."""
+    import cuddhelmholtz_amd as cd
+    from cuddhelmholtz_amd.dist import TraceExchange, native_trace_exchange
+
+    fem = cd.H1Space(cd.Mesh2D.uniform_rect(nx, -1.0, 1.0, nx, -1.0, 1.0), cd.Basis(nb))
+    F = cd.DDH(2 * math.pi * nx / 10, np.ones(fem.size()), fem, nx, nx)
+    info = F.info()
+    B = F.table("B")
+    for rank in range(world):
+        ex = TraceExchange(B, info["n_domains"], info["mx_fdof"], info["n_lambda"], rank, world)
+        owned, send, recv = native_trace_exchange(B, info["n_domains"], info["mx_fdof"], info["n_lambda"], rank, world)
+        assert np.array_equal(owned, ex.owned_slots)
+        assert sorted(send) == sorted(ex.send_slots) and sorted(recv) == sorted(ex.recv_slots)
+        for p in send:
+            assert np.array_equal(send[p], ex.send_slots[p])
+        for p in recv:
+            assert np.array_equal(recv[p], ex.recv_slots[p])

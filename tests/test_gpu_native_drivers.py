@@ -59,6 +59,28 @@ def test_ddh_solve_driver(cuda, tmp_path):
     assert np.isfinite(u_cpp).all() and np.linalg.norm(u_cpp) > 0
 
 
+def test_ddh_solve_driver_multi_gpu_host(cuda, tmp_path):
+    """The same driver through cuddh::ddh_solve_multi_gpu with one device and the communicator forced on: a pure C++ process
+    (no torch: RCCL comes from ROCm's own librccl, bound at run time) must reproduce the single-device solve."""
+    exe = EX / "ddh_solve"
+    if not exe.exists():
+        pytest.fail("build/examples/ddh_solve missing: run __graft_entry__.build()")
+    nx, nb, w_over_pi = 32, 4, 6.4
+    sols = {}
+    for tag, extra in (("plain", []), ("multi", ["1", "1"])):
+        (tmp_path / tag).mkdir()
+        r = subprocess.run([str(exe), str(nx), str(nb), str(w_over_pi), "20", "40", "1e-4", str(tmp_path / tag), *extra], capture_output=True, text=True,
+                           timeout=300)
+        assert r.returncode == 0, r.stderr
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("ddh_solve")][-1]
+        sols[tag] = (np.fromfile(tmp_path / tag / "ddh.0000"), int(re.search(r"num_matvec=(\d+)", line).group(1)), line)
+    assert "devices=1 rccl=1" in sols["multi"][2]
+    assert abs(sols["multi"][1] - sols["plain"][1]) <= 2
+    err = np.linalg.norm(sols["multi"][0] - sols["plain"][0]) / np.linalg.norm(sols["plain"][0])
+    print(f"native driver, multi-GPU host with one rank over RCCL vs plain: {err:.2e}")
+    assert err < 1e-3
+
+
 def test_reference_ddh_example_runs_unchanged(cuda, tmp_path):
     """examples/DDH.cpp of the reference (128^2, degree 3, omega = 2 pi 12.8, GMRES(20), maxit 100, tol 1e-4),
     compiled unchanged against csrc/include/cuddh.hpp."""
@@ -158,3 +180,41 @@ def test_helmholtz_solve_driver(cuda, tmp_path):
     assert out.num_matvec == nmv == 1 + (maxit - 1) * (m + 1)
     assert np.linalg.norm(U_cpp - x.cpu().numpy()) <= 1e-10 * np.linalg.norm(U_cpp)
     assert out.res_norm[-1] < out.res_norm[0]
+
+
+@pytest.mark.parametrize("force_rccl", [False, True])
+def test_multi_gpu_host_one_rank(cuda, force_rccl):
+    """cuddh::ddh_solve_multi_gpu (one process, one host thread and one stream per device, RCCL) with the single device of
+    the test box: with force_rccl the one-rank communicator carries every inner product (ncclAllReduce through the GMRES
+    reduce hook) and the final all-reduce of u -- the code path N > 1 runs -- and the result must be the plain DDH solve's."""
+    import torch
+
+    import cuddhelmholtz_amd as cd
+    from cuddhelmholtz_amd.dist import ddh_solve_multi_gpu
+
+    nx, nb = 32, 4
+    omega = 2 * math.pi * nx / 10
+    mesh = cd.Mesh2D.uniform_rect(nx, -1.0, 1.0, nx, -1.0, 1.0)
+    fem = cd.H1Space(mesh, cd.Basis(nb))
+    n = fem.size()
+    f = torch.zeros(2 * n, dtype=torch.float64, device=cuda)
+    a = torch.zeros(n, dtype=torch.float64, device=cuda)
+    cd.linear_functional(fem, cd.GAUSSIANS, f[:n], param=omega)
+    cd.linear_functional(fem, cd.ALPHA_DISK, a)
+    cd.DiagInvMassMatrix(fem).action(a, a)
+    h_a, h_f = a.cpu().numpy(), f.cpu().numpy()
+    F = cd.DDH(omega, h_a, fem, nx, nx)
+    b = torch.zeros(F.size(), dtype=torch.float32, device=cuda)
+    lam = torch.zeros_like(b)
+    u = torch.zeros_like(f)
+    F.rhs(f, b)
+    out = cd.gmres(F.size(), lam, F, b, 20, 100, 1e-4)
+    F.postprocess(lam, f, u)
+    u_multi, info = ddh_solve_multi_gpu(nx, nb, omega, h_a, h_f, world=1, m=20, maxit=100, tol=1e-4, force_rccl=force_rccl)
+    cd.use_torch_stream()  # the host above ran on its own stream and left this thread on the null stream
+    assert info["world"] == 1 and bool(info["used_rccl"]) == force_rccl and info["success"] == int(out.success) == 1
+    assert abs(info["num_matvec"] - out.num_matvec) <= 2
+    err = float(np.linalg.norm(u_multi - u.cpu().numpy()) / np.linalg.norm(u.cpu().numpy()))
+    print(f"multi-GPU host, one rank, rccl={force_rccl}: {info['num_matvec']} matvecs (plain {out.num_matvec}), u vs plain solve {err:.2e}, "
+          f"t_gmres {info['t_gmres']:.2f} s")
+    assert err < 1e-3
