@@ -129,6 +129,7 @@ _sig("cuddh_hip_helmholtz_plan_destroy", ci, vp)
 _sig("cuddh_hip_helmholtz_apply", ci, vp, cd, vp, vp, vp)
 _sig("cuddh_hip_helmholtz_plan_bytes", cs, vp, ci)
 _sig("cuddh_hip_helmholtz_plan_describe", ci, vp, vp, ci)
+_sig("cuddh_hip_helmholtz_plan_read_stamps", ci, vp, vp, ci)
 _sig("cuddh_hip_operator_plan_create", ci, C.POINTER(vp), ci, ci, ci, ci, vp, vp, ci, vp, vp, vp)
 _sig("cuddh_hip_operator_plan_apply", ci, vp, cd, ci, vp, vp, vp)
 _sig("cuddh_hip_ddh_geom_setup_f32", ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp)
@@ -191,6 +192,7 @@ _sig("cuddh_operator_apply", ci, vp, vp, vp)
 _sig("cuddh_operator_apply_add", ci, vp, cd, vp, vp)
 _sig("cuddh_helmholtz_apply_unfused", ci, vp, vp, vp)
 _sig("cuddh_helmholtz_is_fused", ci, vp)
+_sig("cuddh_helmholtz_read_stamps", ci, vp, vp, ci)
 _sig("cuddh_operator_kernel_name", ci, vp, vp, ci)
 _sig("cuddh_helmholtz_bytes", cs, vp, ci)
 _sig("cuddh_linear_functional", ci, vp, ci, ci, cd, cd, ci, vp)

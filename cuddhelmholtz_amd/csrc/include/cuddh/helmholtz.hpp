@@ -36,6 +36,8 @@ namespace cuddh
 
         /// true when the plan-based kernel is in use (false: fell back to the separate operators)
         bool fused() const { return plan != nullptr; }
+        /// the kernel plan (diagnostics: cuddh_hip_helmholtz_plan_read_stamps)
+        const cuddh_helmholtz_plan *kernel_plan() const { return plan; }
         /// kernel instantiation of the fused apply ("unfused" when it fell back to the separate operators)
         std::string kernel_name() const;
 

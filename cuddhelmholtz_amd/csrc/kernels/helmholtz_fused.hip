@@ -72,6 +72,7 @@ struct cuddh_helmholtz_plan
     int streaming = 0; // metric loads carry the non-temporal hint (plans larger than the infinity cache)
     int lane_form = 0; // fused apply through helm_lane_kernel (one element per lane, both components)
     int prefetch = 0;  // lane form with the whole patch's metric block requested up front (one wavefront per SIMD)
+    unsigned long long *stamps = nullptr; // CUDDH_HELM_STAMPS=1: [n_patches][8] phase time stamps (100 MHz) of the lane form
     size_t bytes_affine = 0; // algorithmic bytes of the affine form (0 when neither metric array is uniform)
 };
 
@@ -102,6 +103,7 @@ namespace
         const double *Gp, *aMp, *aF;
         const double *x;
         double *y, *part;
+        unsigned long long *stamps; // diagnostic: phase time stamps per patch, or null
     };
 
     // Variants measured and dropped: software-pipelined slice loads, slices split between the half-waves
@@ -375,9 +377,16 @@ namespace
             {
                 if (mycol == c)
                 {
+                    // loads first, then adds and stores: see helm_lane_kernel's colour phases
+                    double acc[NN];
 #pragma unroll
                     for (int n = 0; n < NN; ++n)
-                        yc[lix_of(n)] += sgn * out[n];
+                        acc[n] = yc[lix_of(n)];
+                    asm volatile("" ::: "memory"); // all loads before all stores, also in the generated code (the scheduler
+                    __builtin_amdgcn_sched_barrier(0); // otherwise re-serialises them to save registers)
+#pragma unroll
+                    for (int n = 0; n < NN; ++n)
+                        yc[lix_of(n)] = acc[n] + sgn * out[n];
                 }
                 if constexpr (TWO)
                     __builtin_amdgcn_wave_barrier(); // the accumulator is private to the wave: LDS operations of one wave are in order
@@ -499,6 +508,13 @@ namespace
     // ~22 us per patch of exposed latency.  What limits these kernels is the NUMBER of dependent round trips a wavefront makes
     // times the loaded latency (= bytes in flight / bandwidth), so every round trip must carry a full share of the bytes.
     // Kept as a tested option (CUDDH_HELM_PRE=1); the default lane form is the chain with its light round trips merged.
+    // Two further one-wavefront-per-SIMD forms were built on it, measured and removed again (profiles/r02/one_wave_per_simd.txt):
+    // two patches per wavefront with the second patch's requests issued behind the first one's arithmetic (500 registers, no
+    // spills once the slices' FMAs were pinned before the next stage's loads -- the compiler otherwise sinks them to the first
+    // use of the result and keeps every array live: 400 spills) ran 427-463 us, and n_basis 5 in lane form with staged
+    // prefetch 662 us against 428 us for helm_patch_kernel.  A lone wavefront issues one vector instruction every 4 cycles
+    // instead of every 2: the arithmetic of a patch (8 us at n_basis 4) takes twice as long and nothing hides it.  A register
+    // ring of three / four slices in helm_mfma_kernel (n_basis 6-8) also lost (spills at 168 registers: 190 -> 335 us).
     template <int NB, int NQS, int NQM, bool NT, bool UG, bool PRE = false>
     __global__ void __launch_bounds__(64, PRE ? 1 : (NB == 2 ? 5 : (NB == 3 ? 3 : 2))) helm_lane_kernel(HelmArgs A, const double *__restrict__ PS, const double *__restrict__ DS,
                                                               const double *__restrict__ PM, const double *__restrict__ PF,
@@ -512,6 +528,19 @@ namespace
         const int lane = threadIdx.x;
         const int ML = A.max_loc;
         double *xy = lds; // [2][ML]: the gathered x, then the accumulated y
+        // diagnostic phase stamps (wave-uniform branch; the 100 MHz constant clock; every stamp drains the wavefront's memory
+        // operations first and is a compiler barrier, so a phase's time includes the completion of what it issued)
+        auto stamp = [&](int k)
+        {
+            if (A.stamps)
+            {
+                unsigned long long t;
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+                if (lane == 0)
+                    A.stamps[(size_t)patch * 8 + k] = t;
+            }
+        };
+        stamp(0);
 
         const int off = A.dof_off[patch];
         const int nloc = A.dof_off[patch + 1] - off;
@@ -609,6 +638,7 @@ namespace
         for (int base = 64 * ROWS; base < nloc; base += 64 * ROWS)
             gather_pass(base, std::false_type{});
         __syncthreads();
+        stamp(1); // x is in LDS
 
         auto lix_of = [&](int n) -> int { return (n & 1) ? static_cast<int>(lpk[n >> 1] >> 16) : static_cast<int>(lpk[n >> 1] & 0xFFFFu); };
         const double keep = active ? 1.0 : 0.0;
@@ -629,6 +659,7 @@ namespace
             xy[ML + i] = 0.0;
         }
         __syncthreads();
+        stamp(2); // element values in registers
 
         auto stiff_slice = [&](int q, const double (&g)[3 * NQS])
         {
@@ -775,22 +806,58 @@ namespace
             for (int j = 0; j < ROWS; ++j)
                 dest0[j] = slot[min(64 * j + lane, nloc - 1)];
 
+        if (A.stamps)
+        {
+#pragma unroll
+            for (int n = 0; n < NN; ++n)
+                asm volatile("" : "+v"(out[0][n]), "+v"(out[1][n])::"memory"); // the slices' arithmetic is finished
+        }
+        stamp(3); // slices done
         // accumulate in colour phases; the v row is negated (symmetrised system)
         for (int c = 0; c < A.ncol; ++c)
         {
             if (mycol == c)
             {
-#pragma unroll
-                for (int n = 0; n < NN; ++n)
+                // Read every value first, then add and store.  The nodes of an element are distinct dofs, which the compiler
+                // cannot know: written as `xy[l] += ...` per node it waits for each store before the next load -- 32 LDS
+                // round trips in a row, 5.2 us of a wavefront's 36 us (phase stamps, profiles/r02/lane_stamps_before.txt;
+                // 2.2 us afterwards, same-box A/B of the whole apply 389 -> 380 us).  The scheduler re-serialises the batch to
+                // save registers unless fenced.  (n_basis 2 and 3 keep the serial form: their launch bounds leave no registers.)
+                if constexpr (NB >= 4 || PRE)
                 {
-                    const int l = lix_of(n);
-                    xy[l] += out[0][n];
-                    xy[ML + l] -= out[1][n];
+                    double au[NN], av[NN];
+#pragma unroll
+                    for (int n = 0; n < NN; ++n)
+                    {
+                        const int l = lix_of(n);
+                        au[n] = xy[l];
+                        av[n] = xy[ML + l];
+                    }
+                    asm volatile("" ::: "memory"); // all loads before all stores, also in the generated code (the scheduler
+                    __builtin_amdgcn_sched_barrier(0); // otherwise re-serialises them to save registers)
+#pragma unroll
+                    for (int n = 0; n < NN; ++n)
+                    {
+                        const int l = lix_of(n);
+                        xy[l] = au[n] + out[0][n];
+                        xy[ML + l] = av[n] - out[1][n];
+                    }
+                }
+                else
+                {
+#pragma unroll
+                    for (int n = 0; n < NN; ++n)
+                    {
+                        const int l = lix_of(n);
+                        xy[l] += out[0][n];
+                        xy[ML + l] -= out[1][n];
+                    }
                 }
             }
             __syncthreads();
         }
 
+        stamp(4); // colour phases done
         // boundary faces:  Au -= w H v,  Av -= w H u  (lane = face, both rows)
         {
             const int f_begin = A.face_off[patch], nf = A.face_off[patch + 1] - f_begin;
@@ -858,6 +925,7 @@ namespace
             }
         }
 
+        stamp(5); // faces done
         // write out
         for (int base = 0; base < nloc; base += 64 * ROWS)
         {
@@ -884,6 +952,7 @@ namespace
                 }
             }
         }
+        stamp(6); // write-out done (stores complete: the stamp drains them)
     }
 
     __global__ void __launch_bounds__(256) helm_border_kernel(int n_shared, int ndof, int n_slots, const int *__restrict__ shared_dof,
@@ -1107,6 +1176,7 @@ namespace
         A.x = x;
         A.y = y;
         A.part = p->part;
+        A.stamps = p->stamps;
         return A;
     }
 
@@ -1310,9 +1380,15 @@ namespace
             {
                 if (mycol == c)
                 {
+                    double acc[NN]; // loads first, then adds and stores (see helm_lane_kernel)
 #pragma unroll
                     for (int n = 0; n < NN; ++n)
-                        yc[lix_of(n)] += out[n];
+                        acc[n] = yc[lix_of(n)];
+                    asm volatile("" ::: "memory"); // all loads before all stores, also in the generated code (the scheduler
+                    __builtin_amdgcn_sched_barrier(0); // otherwise re-serialises them to save registers)
+#pragma unroll
+                    for (int n = 0; n < NN; ++n)
+                        yc[lix_of(n)] = acc[n] + out[n];
                 }
                 __syncthreads();
             }
@@ -1571,9 +1647,15 @@ namespace
                 for (int s = 0; s < 2; ++s)
                     if (g + 4 * s < NB)
                     {
+                        double acc[NB]; // loads first, then adds and stores (see helm_lane_kernel)
 #pragma unroll
                         for (int l = 0; l < NB; ++l)
-                            ys[id[s][l]] += OUT[s][l];
+                            acc[l] = ys[id[s][l]];
+                        asm volatile("" ::: "memory"); // all loads before all stores, also in the generated code (the scheduler
+                        __builtin_amdgcn_sched_barrier(0); // otherwise re-serialises them to save registers)
+#pragma unroll
+                        for (int l = 0; l < NB; ++l)
+                            ys[id[s][l]] = acc[l] + OUT[s][l];
                     }
             }
             __syncthreads();
@@ -1852,9 +1934,15 @@ namespace
                 for (int s = 0; s < 2; ++s)
                     if (g + 4 * s < NB)
                     {
+                        double acc[NB]; // loads first, then adds and stores (see helm_lane_kernel)
 #pragma unroll
                         for (int l = 0; l < NB; ++l)
-                            xy[cmp * ML + id[s][l]] += (cmp ? -OUT[0][s][l] : OUT[0][s][l]);
+                            acc[l] = xy[cmp * ML + id[s][l]];
+                        asm volatile("" ::: "memory"); // all loads before all stores, also in the generated code (the scheduler
+                        __builtin_amdgcn_sched_barrier(0); // otherwise re-serialises them to save registers)
+#pragma unroll
+                        for (int l = 0; l < NB; ++l)
+                            xy[cmp * ML + id[s][l]] = acc[l] + (cmp ? -OUT[0][s][l] : OUT[0][s][l]);
                     }
             }
             __syncthreads();
@@ -2031,7 +2119,7 @@ extern "C"
             return 0;
         void *ptrs[] = {p->dof_off, p->dof_list, p->slot_of, p->patch_nel, p->lidx, p->colour, p->Gp, p->aMp, p->Gu, p->au, p->Gm, p->Am, p->face_off,
                         p->face_lidx, p->face_id, p->face_col, p->PS, p->DS, p->PM, p->PF, p->shared_dof, p->shared_off,
-                        p->part};
+                        p->part, p->stamps};
         for (void *q : ptrs)
             if (q)
                 (void)hipFree(q);
@@ -2388,6 +2476,9 @@ extern "C"
             (*out)->prefetch = 0;
             if (const char *e = std::getenv("CUDDH_HELM_PRE"))
                 (*out)->prefetch = (*out)->lane_form && std::atoi(e) != 0;
+            if (std::getenv("CUDDH_HELM_STAMPS") && (*out)->lane_form) // diagnostic, see cuddh_hip_helmholtz_plan_read_stamps
+                if (hipMalloc(reinterpret_cast<void **>(&(*out)->stamps), (size_t)(*out)->n_patches * 8 * sizeof(unsigned long long)) == hipSuccess)
+                    (void)hipMemset((*out)->stamps, 0, (size_t)(*out)->n_patches * 8 * sizeof(unsigned long long));
         }
         return err;
     }
@@ -2504,6 +2595,14 @@ extern "C"
             err = launch_status();
         }
         return err;
+    }
+
+    // diagnostic (CUDDH_HELM_STAMPS=1 at plan creation): copies the [n_patches][8] phase stamps of the last lane-form apply
+    int cuddh_hip_helmholtz_plan_read_stamps(const cuddh_helmholtz_plan *p, unsigned long long *h_out, int n_patches)
+    {
+        if (!p || !p->stamps || n_patches > p->n_patches)
+            return static_cast<int>(hipErrorInvalidValue);
+        return static_cast<int>(hipMemcpy(h_out, p->stamps, (size_t)n_patches * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     }
 
     int cuddh_hip_helmholtz_plan_describe(const cuddh_helmholtz_plan *p, char *buf, int cap)

@@ -498,6 +498,13 @@ extern "C"
             std::snprintf(buf, cap, "%s", name.c_str());
         });
     }
+    int cuddh_helmholtz_read_stamps(void *op, unsigned long long *h_out, int n_patches)
+    {
+        auto *h = static_cast<OpHandle *>(op);
+        if (!h->helm)
+            return -1;
+        return cuddh_hip_helmholtz_plan_read_stamps(h->helm->kernel_plan(), h_out, n_patches);
+    }
     size_t cuddh_helmholtz_bytes(void *op, int actual)
     {
         auto *h = static_cast<OpHandle *>(op);

@@ -90,6 +90,8 @@ int cuddh_helmholtz_apply_unfused(void *op, const double *x, double *y);
 int cuddh_helmholtz_is_fused(void *op);
 /* kernel instantiation the operator's action() launches (Helmholtz, Stiffness, Mass; "generic"/"unfused" otherwise) */
 int cuddh_operator_kernel_name(void *op, char *buf, int cap);
+/* diagnostic: phase time stamps of the last fused apply, see cuddh_hip_helmholtz_plan_read_stamps */
+int cuddh_helmholtz_read_stamps(void *op, unsigned long long *h_out, int n_patches);
 size_t cuddh_helmholtz_bytes(void *op, int actual); /* actual: 0 / 1 / 2 as cuddh_hip_helmholtz_plan_bytes */
 
 /* ---- load vectors with built-in integrands (device lambdas cannot cross a C ABI).

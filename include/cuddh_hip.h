@@ -171,6 +171,9 @@ size_t cuddh_hip_helmholtz_plan_bytes(const cuddh_helmholtz_plan *plan, int actu
 /* which kernel instantiation the plan's apply launches, e.g. "helm_lane_kernel<4,5,8,NT=1,UG=0> pe=64" (tests assert
  * the form they mean to exercise; bench.py reports it instead of re-deriving the size rules) */
 int cuddh_hip_helmholtz_plan_describe(const cuddh_helmholtz_plan *plan, char *buf, int cap);
+/* diagnostic: with CUDDH_HELM_STAMPS=1 in the environment at plan creation the lane-form kernels record 8 phase time stamps
+ * (100 MHz constant clock) per patch; this copies those of the last apply to h_out ([n_patches][8]). */
+int cuddh_hip_helmholtz_plan_read_stamps(const cuddh_helmholtz_plan *plan, unsigned long long *h_out, int n_patches);
 
 /* The same plan machinery for ONE real operator -- the bandwidth path of StiffnessMatrix::action
  * (source/StiffnessMatrix.cpp:186-205, kind 0, metric = G (3,nq,nq,n_elem)) and MassMatrix::action

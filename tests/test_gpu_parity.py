@@ -393,7 +393,7 @@ def test_patch_sizes_agree(cuda, kind, nx, nb, monkeypatch):
                     monkeypatch.setenv("CUDDH_OP_PE", "64")
                     monkeypatch.delenv("CUDDH_HELM_PE", raising=False)
                     monkeypatch.setenv("CUDDH_HELM_LANE", "1")
-                    monkeypatch.setenv("CUDDH_HELM_PRE", "1" if pe == "lane" else "0")
+                    monkeypatch.setenv("CUDDH_HELM_PRE", {"lane": "1", "lane0": "0"}[pe])
                 else:
                     monkeypatch.setenv("CUDDH_OP_PE", pe)
                     monkeypatch.setenv("CUDDH_HELM_PE", pe)
@@ -415,15 +415,16 @@ def test_patch_sizes_agree(cuda, kind, nx, nb, monkeypatch):
                 assert A.fused()
                 # which instantiation ran
                 ug = int(kind == "structured" and affine == "1")  # uniform stiffness metric, read through scalar loads
-                ope = 64 if pe.startswith("lane") else int(pe)
+                lane_like = pe.startswith("lane")
+                ope = 64 if lane_like else int(pe)
                 assert S.kernel() == f"op_patch_kernel<{nb},{nqS},0,NT={0 if ug else int(nt)},UG={ug},PEK={ope}> pe={ope}", S.kernel()
                 assert M.kernel() == f"op_patch_kernel<{nb},{nqM},1,NT={nt},UG=0,PEK={ope}> pe={ope}", M.kernel()  # a2 varies: never uniform
-                if pe.startswith("lane") and nb <= 4 and (not ug or nb == 2):
-                    want = f"helm_lane_kernel<{nb},{nqS},{nqM},NT={nt},UG={ug}{',PRE=1' if pe == 'lane' else ''}> pe=64"
+                if lane_like and nb <= 4 and (not ug or nb == 2):
+                    want = f"helm_lane_kernel<{nb},{nqS},{nqM},NT={nt},UG={ug}{',PRE=1' if pe != 'lane0' else ''}> pe=64"
                 else:
                     # forced sizes apply to n_basis <= 4; affine plans are 64-element ones unless forced; a lane request that
                     # does not apply (affine n_basis 3, 4; n_basis 5) leaves the default size
-                    hpe = (int(pe) if not pe.startswith("lane") else (64 if ug else 32)) if nb <= 4 else 32
+                    hpe = (int(pe) if not lane_like else (64 if ug else 32)) if nb <= 4 else 32
                     want = f"helm_patch_kernel<{nb},{nqS},{nqM},NT={nt},UG={ug},PEK={hpe}> pe={hpe}"
                 assert A.kernel() == want, (A.kernel(), want)
                 seen.add(A.kernel())
