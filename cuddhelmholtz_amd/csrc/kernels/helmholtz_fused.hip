@@ -72,6 +72,7 @@ struct cuddh_helmholtz_plan
     int streaming = 0; // metric loads carry the non-temporal hint (plans larger than the infinity cache)
     int lane_form = 0; // fused apply through helm_lane_kernel (one element per lane, both components)
     int prefetch = 0;  // lane form with the whole patch's metric block requested up front (one wavefront per SIMD)
+    int pair_layout = 0; // metric slices stored as [pairs of values][64 lanes][2] (+ one single row): 16-byte loads (lane form)
     unsigned long long *stamps = nullptr; // CUDDH_HELM_STAMPS=1: [n_patches][8] phase time stamps (100 MHz) of the lane form
     size_t bytes_affine = 0; // algorithmic bytes of the affine form (0 when neither metric array is uniform)
 };
@@ -90,6 +91,30 @@ namespace
             return __builtin_nontemporal_load(p);
         else
             return *p;
+    }
+
+    // 16-byte metric loads.  A slice of NV values per element is stored as NV/2 pairs, [pair][64 lanes][2 doubles], followed
+    // by one [64 lanes] row when NV is odd: a wavefront's load instruction then moves 1 KiB instead of 512 B.  On the metric
+    // stream alone (profiles/tools/dma_stream.hip, 8 wavefronts per CU, one slice per round trip) that is 5.7 against 4.6 TB/s.
+    typedef double dbl2_t __attribute__((ext_vector_type(2)));
+    template <int NV, bool NT>
+    __device__ inline void load_pairs(const double *__restrict__ slice, int lane, double (&v)[NV])
+    {
+        constexpr int VP = NV / 2;
+        const dbl2_t *p2 = reinterpret_cast<const dbl2_t *>(slice) + lane;
+#pragma unroll
+        for (int k = 0; k < VP; ++k)
+        {
+            dbl2_t t;
+            if constexpr (NT)
+                t = __builtin_nontemporal_load(p2 + k * 64);
+            else
+                t = p2[k * 64];
+            v[2 * k] = t.x;
+            v[2 * k + 1] = t.y;
+        }
+        if constexpr (NV % 2 == 1)
+            v[NV - 1] = metric_load<NT>(slice + 2 * VP * 64 + lane);
     }
 
     struct HelmArgs
@@ -545,8 +570,8 @@ namespace
         const int off = A.dof_off[patch];
         const int nloc = A.dof_off[patch + 1] - off;
         const int *dofs = A.dof_list + off;
-        const double *Gp = A.Gp + (size_t)patch * 3 * NQS * NQS * PEK + lane;
-        const double *ap = A.aMp + (size_t)patch * NQM * NQM * PEK + lane;
+        const double *Gp = A.Gp + (size_t)patch * 3 * NQS * NQS * PEK; // pair layout, see load_pairs
+        const double *ap = A.aMp + (size_t)patch * NQM * NQM * PEK;
 
         const bool active = lane < A.patch_nel[patch];
         const uint32_t *li = A.lidx + ((size_t)patch * NP) * PEK + lane;
@@ -557,12 +582,26 @@ namespace
         const int mycol = active ? A.colour[patch * PEK + lane] : -1;
         auto load_stiff = [&](int q, double (&g)[3 * NQS])
         {
+            if constexpr (UG)
+            {
 #pragma unroll
-            for (int r = 0; r < NQS; ++r)
+                for (int r = 0; r < NQS; ++r)
 #pragma unroll
-                for (int c = 0; c < 3; ++c)
-                    g[3 * r + c] = UG ? GU[(q * 3 + c) * NQS + r] : metric_load<NT>(&Gp[((q * 3 + c) * NQS + r) * PEK]);
+                    for (int c = 0; c < 3; ++c)
+                        g[3 * r + c] = GU[(q * 3 + c) * NQS + r];
+            }
+            else
+            {
+                double v[3 * NQS]; // memory order of a slice: v = c * NQS + r
+                load_pairs<3 * NQS, NT>(Gp + (size_t)q * 3 * NQS * PEK, lane, v);
+#pragma unroll
+                for (int r = 0; r < NQS; ++r)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c)
+                        g[3 * r + c] = v[c * NQS + r];
+            }
         };
+        auto load_mass = [&](int q, double (&am)[NQM]) { load_pairs<NQM, NT>(ap + (size_t)q * NQM * PEK, lane, am); };
         // The chain form requests the first TWO stiffness slices before the gather: the element state (u, out: 8 NB^2 registers)
         // is not live yet, so the registers are there, and the two light round trips of the gather (dof indices, then x
         // values) each carry a slice instead of one of them carrying nothing.  The write-out's destination indices ride
@@ -618,9 +657,7 @@ namespace
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int q = 0; q < NQM; ++q)
-#pragma unroll
-                    for (int r = 0; r < NQM; ++r)
-                        aW[q][r] = metric_load<NT>(&ap[(q * NQM + r) * PEK]);
+                    load_mass(q, aW[q]);
                 __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
@@ -783,21 +820,15 @@ namespace
         for (int q = PRE ? NQM : 0; q + 1 < NQM; q += 2)
         {
             double am0[NQM], am1[NQM];
-#pragma unroll
-            for (int r = 0; r < NQM; ++r)
-            {
-                am0[r] = metric_load<NT>(&ap[(q * NQM + r) * PEK]);
-                am1[r] = metric_load<NT>(&ap[((q + 1) * NQM + r) * PEK]);
-            }
+            load_mass(q, am0);
+            load_mass(q + 1, am1);
             mass_slice(q, am0);
             mass_slice(q + 1, am1);
         }
         if constexpr (NQM % 2 == 1 && !PRE)
         {
             double am[NQM];
-#pragma unroll
-            for (int r = 0; r < NQM; ++r)
-                am[r] = metric_load<NT>(&ap[((NQM - 1) * NQM + r) * PEK]);
+            load_mass(NQM - 1, am);
             mass_slice(NQM - 1, am);
         }
 
@@ -1053,8 +1084,10 @@ namespace
     }
 
     // reference layout (c, q, r, el) -> [patch][q][c][r][32]
+    // pair != 0: within a slice (patch, q) the comps*nq values v = c*nq + r are stored as pairs, [v/2][pe lanes][2], the last one
+    // of an odd count as a [pe lanes] row behind them (load_pairs)
     __global__ void __launch_bounds__(256) repack_kernel(long long total, int comps, int nq, int pe, const int *__restrict__ perm,
-                                                        const double *__restrict__ src, double *__restrict__ dst)
+                                                        const double *__restrict__ src, double *__restrict__ dst, int pair)
     {
         for (long long t = blockIdx.x * 256LL + threadIdx.x; t < total; t += gridDim.x * 256LL)
         {
@@ -1067,7 +1100,15 @@ namespace
             const int q = static_cast<int>(rest % nq);
             const long long patch = rest / nq;
             const int el = perm[patch * pe + le];
-            dst[t] = el >= 0 ? src[c + (size_t)comps * ((q + (size_t)nq * r) + (size_t)nq * nq * el)] : 0.0;
+            const double val = el >= 0 ? src[c + (size_t)comps * ((q + (size_t)nq * r) + (size_t)nq * nq * el)] : 0.0;
+            if (!pair)
+                dst[t] = val;
+            else
+            {
+                const int nv = comps * nq, v = c * nq + r, vp = nv / 2;
+                const long long slice = (patch * nq + q) * (long long)nv * pe;
+                dst[v < 2 * vp ? slice + ((long long)(v / 2) * pe + le) * 2 + (v & 1) : slice + (long long)2 * vp * pe + le] = val;
+            }
         }
     }
 
@@ -2131,7 +2172,7 @@ extern "C"
     static int build_plan(cuddh_helmholtz_plan **out, int ndof, int n_elem, int nb, const int *h_I, const double *h_xy, int nqS,
                           const double *h_PS, const double *h_DS, const double *G_S, int nqM, const double *h_PM, const double *a_M,
                           int n_faces, const int *h_fI, const int *h_face_elem, int nqF, const double *h_PF, const double *a_F,
-                          int pe = PE)
+                          int pe = PE, bool want_pairs = false)
     {
         *out = nullptr;
         const bool mfma = pe == 16; // 16-element batches: the matrix-core kernels
@@ -2368,6 +2409,9 @@ extern "C"
             if (d_zero)
                 ok(static_cast<int>(hipMemset(d_zero, 0, (size_t)pe * sizeof(int))));
         }
+        // the lane form of the fused apply (64-element patches, general geometry -- or the affine n_basis-2 form, whose mass
+        // weights are still per element) reads its slices with 16-byte loads
+        p->pair_layout = (want_pairs && !mfma && pe == 64 && nqS > 0 && nqM > 0 && (!p->Gu || nb == 2)) ? 1 : 0;
         const long long nG = p->Gu ? 0 : (long long)(uniform_G ? 1 : n_patches) * 3 * nqS * nqS * pe;
         const long long nA = p->au ? 0 : (long long)(uniform_a ? 1 : n_patches) * nqM * nqM * pe;
         if (nG > 0)
@@ -2380,12 +2424,12 @@ extern "C"
                 hipLaunchKernelGGL(repack_mfma_kernel, dim3(stream_grid(nG, 256)), dim3(256), 0, nullptr, nG, 3, nqS, uniform_G ? d_zero : d_perm, G_S,
                                    p->Gm);
             else if (nG > 0)
-                hipLaunchKernelGGL(repack_kernel, dim3(stream_grid(nG, 256)), dim3(256), 0, nullptr, nG, 3, nqS, pe, d_perm, G_S, p->Gp);
+                hipLaunchKernelGGL(repack_kernel, dim3(stream_grid(nG, 256)), dim3(256), 0, nullptr, nG, 3, nqS, pe, d_perm, G_S, p->Gp, p->pair_layout);
             if (nA > 0 && mfma)
                 hipLaunchKernelGGL(repack_mfma_kernel, dim3(stream_grid(nA, 256)), dim3(256), 0, nullptr, nA, 1, nqM, uniform_a ? d_zero : d_perm, a_M,
                                    p->Am);
             else if (nA > 0)
-                hipLaunchKernelGGL(repack_kernel, dim3(stream_grid(nA, 256)), dim3(256), 0, nullptr, nA, 1, nqM, pe, d_perm, a_M, p->aMp);
+                hipLaunchKernelGGL(repack_kernel, dim3(stream_grid(nA, 256)), dim3(256), 0, nullptr, nA, 1, nqM, pe, d_perm, a_M, p->aMp, p->pair_layout);
             ok(launch_status());
             ok(static_cast<int>(hipDeviceSynchronize()));
         }
@@ -2465,10 +2509,10 @@ extern "C"
         if (lane_form)
             pe = 64;
         const int err = build_plan(out, ndof, n_elem, nb, h_I, h_xy, nqS, h_PS, h_DS, G_S, nqM, h_PM, a_M, n_faces, h_fI, h_face_elem, nqF,
-                                   h_PF, a_F, pe);
+                                   h_PF, a_F, pe, lane_form);
         if (!err && *out)
         {
-            (*out)->lane_form = lane_form && (!(*out)->Gu || affine_lane);
+            (*out)->lane_form = (*out)->pair_layout; // = lane_form && (general geometry || affine n_basis 2): decided in build_plan
             // the lane form with the whole metric block in the register file (PRE, one wavefront per SIMD): measured SLOWER
             // than the slice-by-slice chain at two wavefronts per SIMD (1024^2, n_basis 4: 434-442 vs 373-376 us), although
             // the metric stream alone runs at 6.46 TB/s that way -- see the comment at the kernel.  CUDDH_HELM_PRE=1 selects it

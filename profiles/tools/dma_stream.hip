@@ -55,6 +55,33 @@ __global__ void __launch_bounds__(64, 2) reg_kernel(const double *__restrict__ M
     out[(size_t)patch * 64 + threadIdx.x] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
 }
 
+// the slice chain with 16-byte loads: layout [slice][8 pairs][64 lanes][2] instead of [slice][15 rows][64 lanes]; a slice is 8 load
+// instructions of 1 KiB (16 values per lane) instead of 15 of 512 B
+typedef double dbl2v __attribute__((ext_vector_type(2)));
+__global__ void __launch_bounds__(64, 2) reg16_kernel(const double *__restrict__ M, double *__restrict__ out, int n_patches, int rows, int chunk)
+{
+    const int patch = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+    if (patch >= n_patches)
+        return;
+    const dbl2v *p = reinterpret_cast<const dbl2v *>(M + (size_t)patch * rows * 64) + threadIdx.x;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int r0 = 0; r0 < rows; r0 += 16)
+    {
+        dbl2v g[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+            g[r] = (r0 + 2 * r < rows) ? __builtin_nontemporal_load(&p[(size_t)(r0 / 2 + r) * 64]) : dbl2v{0.0, 0.0};
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+            if (r0 + 2 * r < rows)
+            {
+                work(acc, g[r].x);
+                work(acc, g[r].y);
+            }
+    }
+    out[(size_t)patch * 64 + threadIdx.x] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+}
+
 // whole block requested up front (ROWS x 2 registers per lane, the register file of a SIMD that holds ONE wavefront has
 // 512 per lane: 256 VGPR + 256 AGPR), consumed in order: the loads run as far ahead as the memory system allows
 template <int ROWS>
@@ -207,6 +234,13 @@ int main(int argc, char **argv)
         char name[96];
         std::snprintf(name, sizeof name, "reg chain, %d waves/CU (LDS-limited)", wpc);
         time(name, [&] { hipLaunchKernelGGL(reg_kernel, dim3(8 * chunk), dim3(64), 163840 / wpc - 256, 0, M, out, n_patches, rows, chunk); });
+    }
+    CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(reg16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+    for (int wpc : {8, 12, 16})
+    {
+        char name[96];
+        std::snprintf(name, sizeof name, "reg chain 16 B/lane, %d waves/CU", wpc);
+        time(name, [&] { hipLaunchKernelGGL(reg16_kernel, dim3(8 * chunk), dim3(64), 163840 / wpc - 256, 0, M, out, n_patches, rows, chunk); });
     }
     if (rows == 140)
     {
