@@ -114,6 +114,7 @@ _sig("cuddh_hip_trace_pack_f32", ci, ci, ci, vp, vp, vp, ci, vp)
 _sig("cuddh_hip_trace_pack_f64", ci, ci, ci, vp, vp, vp, ci, vp)
 _sig("cuddh_hip_trace_unpack_f32", ci, ci, ci, vp, vp, vp, vp)
 _sig("cuddh_hip_trace_unpack_f64", ci, ci, ci, vp, vp, vp, vp)
+_sig("cuddh_hip_csr_sum_f64", ci, ci, vp, vp, vp, vp, ci, vp)
 _sig("cuddh_hip_zero_indexed_f64", ci, ci, vp, vp, vp)
 _sig("cuddh_hip_element_metrics", ci, ci, ci, vp, vp, vp, vp, vp, vp)
 _sig("cuddh_hip_stiffness_setup", ci, ci, ci, vp, vp, vp, vp)
@@ -138,6 +139,7 @@ _sig("cuddh_hip_ddh_plan_create", ci, C.POINTER(vp), C.POINTER(DdhDesc), ci, ci)
 _sig("cuddh_hip_ddh_plan_destroy", ci, vp)
 _sig("cuddh_hip_ddh_plan_kernel", ci, vp)
 _sig("cuddh_hip_ddh_plan_set_wh_iters", ci, vp, ci)
+_sig("cuddh_hip_ddh_plan_set_vector_layout", ci, vp, vp, ci)
 _sig("cuddh_hip_ddh_apply_f32", ci, vp, ci, ci, vp, vp, ci, vp, vp, vp)
 _sig("cuddh_hip_ddh_apply_f64", ci, vp, ci, ci, vp, vp, ci, vp, vp, vp)
 

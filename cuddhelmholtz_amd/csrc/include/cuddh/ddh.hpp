@@ -72,6 +72,8 @@ namespace cuddh
             /// device-side part of the set-up (geometric factors, kernel plan); deferred to first use so
             /// that the host tables can be built and inspected without a GPU
             void ensure_plan() const;
+            /// tables of the fixed-order assembly of y (first call with y != nullptr)
+            void ensure_assembly() const;
 
             int g_ndof, g_elem, n_basis, n_domains, n_lambda, nt, mx_dof, mx_fdof, mx_elem_per_dom, nel1d;
             double omega, dt;
@@ -84,6 +86,11 @@ namespace cuddh
             mutable HostDeviceArray<Real> _g_tensor;
             std::unique_ptr<EnsembleSpace> efem;
             mutable cuddh_ddh_plan *plan = nullptr;
+            // y = sum over subdomains of weighted local solutions, assembled in a fixed order instead of with atomics:
+            // identity numbering of the subdomain dofs, their forcing / solution in that numbering, and per global dof the
+            // list of subdomain dofs that are copies of it (increasing subdomain, like the reference's serial meaning)
+            mutable host_device_ivec _gI_local, _csr_off, _csr_src;
+            mutable host_device_dvec _x_local, _y_local;
         };
     } // namespace detail
 

@@ -21,6 +21,89 @@
 
 namespace cuddh
 {
+    namespace detail
+    {
+        /// Contiguous store of mesh entities whose slots can be constructed in parallel: std::vector value-initialises on one
+        /// thread (0.4 GB of nodes, edges and elements at 1024^2: 0.08 s of a 0.1 s mesh).  `claim(n)` allocates n raw slots that
+        /// the caller constructs with placement new (every slot exactly once); push_back grows like a vector.
+        template <typename T>
+        class EntityStore
+        {
+        public:
+            EntityStore() = default;
+            EntityStore(const EntityStore &) = delete;
+            EntityStore &operator=(const EntityStore &) = delete;
+            EntityStore(EntityStore &&o) noexcept : p(o.p), n(o.n), cap(o.cap) { o.p = nullptr; o.n = o.cap = 0; }
+            EntityStore &operator=(EntityStore &&o) noexcept
+            {
+                if (this != &o)
+                {
+                    release();
+                    p = o.p;
+                    n = o.n;
+                    cap = o.cap;
+                    o.p = nullptr;
+                    o.n = o.cap = 0;
+                }
+                return *this;
+            }
+            ~EntityStore() { release(); }
+
+            std::size_t size() const { return n; }
+            T &operator[](std::size_t i) { return p[i]; }
+            const T &operator[](std::size_t i) const { return p[i]; }
+            T *begin() { return p; }
+            T *end() { return p + n; }
+            const T *begin() const { return p; }
+            const T *end() const { return p + n; }
+
+            /// n raw slots (the store must be empty); the caller placement-constructs each of them
+            T *claim(std::size_t count)
+            {
+                release();
+                p = static_cast<T *>(::operator new(count * sizeof(T)));
+                n = cap = count;
+                return p;
+            }
+            /// value-constructed slots, on this thread (the generic from_vertices path)
+            void resize(std::size_t count)
+            {
+                T *q = claim(count);
+                for (std::size_t i = 0; i < count; ++i)
+                    new (q + i) T();
+            }
+            void push_back(const T &v)
+            {
+                if (n == cap)
+                {
+                    const std::size_t ncap = cap ? 2 * cap : 1024;
+                    T *q = static_cast<T *>(::operator new(ncap * sizeof(T)));
+                    for (std::size_t i = 0; i < n; ++i)
+                    {
+                        new (q + i) T(std::move(p[i]));
+                        p[i].~T();
+                    }
+                    ::operator delete(p);
+                    p = q;
+                    cap = ncap;
+                }
+                new (p + n++) T(v);
+            }
+
+        private:
+            void release()
+            {
+                for (std::size_t i = 0; i < n; ++i)
+                    p[i].~T();
+                ::operator delete(p);
+                p = nullptr;
+                n = cap = 0;
+            }
+            T *p = nullptr;
+            std::size_t n = 0, cap = 0;
+        };
+    } // namespace detail
+
     class Mesh2D
     {
     public:
@@ -126,9 +209,9 @@ namespace cuddh
 
         // contiguous stores (the reference keeps one heap object per edge and element, include/Mesh2D.hpp:283-285;
         // straight edges and bilinear quadrilaterals are the only kinds either code has)
-        std::vector<Node> _nodes;
-        std::vector<StraightEdge> _edges;
-        std::vector<QuadElement> _elements;
+        detail::EntityStore<Node> _nodes;
+        detail::EntityStore<StraightEdge> _edges;
+        detail::EntityStore<QuadElement> _elements;
         std::vector<int> _interior_nodes, _boundary_nodes;
         std::vector<int> _boundary_edges, _interior_edges;
 

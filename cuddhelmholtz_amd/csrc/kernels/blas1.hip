@@ -457,6 +457,19 @@ namespace
         }
     }
 
+    // y[r] = (accumulate ? y[r] : 0) + sum_{k in [off[r], off[r+1])} x[src[k]], the terms added in the order they are listed
+    __global__ void __launch_bounds__(BLOCK) csr_sum_kernel(int n_rows, const int *__restrict__ off, const int *__restrict__ src, const double *__restrict__ x,
+                                                            double *__restrict__ y, int accumulate)
+    {
+        for (int r = blockIdx.x * BLOCK + threadIdx.x; r < n_rows; r += gridDim.x * BLOCK)
+        {
+            double s = accumulate ? y[r] : 0.0;
+            for (int k = off[r]; k < off[r + 1]; ++k)
+                s += x[src[k]];
+            y[r] = s;
+        }
+    }
+
     __global__ void __launch_bounds__(BLOCK) diag_scale_kernel(int n, int accumulate, double c, const double *__restrict__ p, const double *x, double *y)
     {
         // x may alias y (DiagInvMassMatrix is applied in place by the DDH example)
@@ -577,6 +590,12 @@ extern "C"
         if (n > 0)
             hipLaunchKernelGGL((trace_unpack_kernel<double>), dim3(stream_grid(n, BLOCK)), dim3(BLOCK), 0, as_stream(s), n, n_half, slot, buf, v);
         return n > 0 ? launch_status() : 0;
+    }
+    int cuddh_hip_csr_sum_f64(int n_rows, const int *off, const int *src, const double *x, double *y, int accumulate, void *s)
+    {
+        if (n_rows > 0)
+            hipLaunchKernelGGL(csr_sum_kernel, dim3(stream_grid(n_rows, BLOCK)), dim3(BLOCK), 0, as_stream(s), n_rows, off, src, x, y, accumulate);
+        return n_rows > 0 ? launch_status() : 0;
     }
     int cuddh_hip_zero_indexed_f64(int n, const int *proj, double *x, void *s)
     {

@@ -29,6 +29,8 @@ struct cuddh_ddh_plan
                 // 5 dense element matrix on the matrix cores (fp32, uniform geometry)
     int nodes;  // nb*nb*nel1d*nel1d
     int wh_iters = 5; // WaveHoltz iterations per local solve (source/DDH.cpp:136); WH_ITERS_REFERENCE
+    const int *gI_override = nullptr; // cuddh_hip_ddh_plan_set_vector_layout: x and y in another numbering than d.gI
+    int g_ndof_override = 0;
     float *Aop = nullptr; // kernel 5: element stiffness matrix as MFMA A operands, [4 k-steps][64 lanes]
     float *Sep = nullptr; // kernel 7: [Ax | Ay | beta | gamma] of the separable nb = 8 sweep
 };
@@ -1397,9 +1399,10 @@ namespace
         if (dom_begin < 0 || dom_end > d.n_domains || dom_begin > dom_end)
             return static_cast<int>(hipErrorInvalidValue);
         hipStream_t st = as_stream(stream);
+        const int g_ndof = plan->gI_override ? plan->g_ndof_override : d.g_ndof;
         if (y && zero_y)
         {
-            hipError_t e = hipMemsetAsync(y, 0, (size_t)2 * d.g_ndof * sizeof(double), st);
+            hipError_t e = hipMemsetAsync(y, 0, (size_t)2 * g_ndof * sizeof(double), st);
             if (e != hipSuccess)
                 return static_cast<int>(e);
         }
@@ -1408,7 +1411,7 @@ namespace
             return 0;
 
         DdhArgs<Real> A;
-        A.g_ndof = d.g_ndof;
+        A.g_ndof = g_ndof;
         A.n_lambda = d.n_lambda;
         A.nt = d.nt;
         A.wh_iters = plan->wh_iters;
@@ -1422,7 +1425,7 @@ namespace
         A.s_dof = d.s_dof;
         A.s_fdof = d.s_fdof;
         A.B = d.B;
-        A.gI = d.gI;
+        A.gI = plan->gI_override ? plan->gI_override : d.gI;
         A.sI = d.sI;
         A.G = static_cast<const Real *>(d.G);
         A.m = static_cast<const Real *>(d.m);
@@ -1628,6 +1631,15 @@ extern "C"
     }
 
     int cuddh_hip_ddh_plan_kernel(const cuddh_ddh_plan *plan) { return plan ? plan->kernel : 0; }
+
+    int cuddh_hip_ddh_plan_set_vector_layout(cuddh_ddh_plan *plan, const int *d_gI, int g_ndof)
+    {
+        if (!plan || (d_gI && g_ndof <= 0))
+            return static_cast<int>(hipErrorInvalidValue);
+        plan->gI_override = d_gI;
+        plan->g_ndof_override = d_gI ? g_ndof : 0;
+        return 0;
+    }
 
     int cuddh_hip_ddh_plan_set_wh_iters(cuddh_ddh_plan *plan, int wh_iters)
     {

@@ -370,15 +370,85 @@ namespace cuddh
         }
 
         template <typename Real>
+        void DDHCore<Real>::ensure_assembly() const
+        {
+            if (_csr_off.size() > 0)
+                return;
+            const int N = mx_dof * n_domains;
+            const int *gi = _gI.host_read();
+            auto sizes = efem->sizes(MemorySpace::HOST);
+            _gI_local.resize(N);
+            int *loc = _gI_local.host_write();
+            parallel_for(static_cast<std::size_t>(N), [&](std::size_t i0, std::size_t i1, int)
+            {
+                for (std::size_t i = i0; i < i1; ++i)
+                    loc[i] = static_cast<int>(i);
+            });
+            _csr_off.resize(g_ndof + 1);
+            int *off = _csr_off.host_write();
+            std::fill(off, off + g_ndof + 1, 0);
+            for (int s = 0; s < n_domains; ++s)
+                for (int l = 0; l < sizes(s); ++l)
+                    ++off[gi[l + static_cast<std::size_t>(mx_dof) * s] + 1];
+            for (int g = 0; g < g_ndof; ++g)
+                off[g + 1] += off[g];
+            _csr_src.resize(off[g_ndof]);
+            int *src = _csr_src.host_write();
+            std::vector<int> fill(off, off + g_ndof);
+            for (int s = 0; s < n_domains; ++s) // increasing subdomain: the order of a serial loop over the subdomains
+                for (int l = 0; l < sizes(s); ++l)
+                    src[fill[gi[l + static_cast<std::size_t>(mx_dof) * s]]++] = l + mx_dof * s;
+            _x_local.resize(2 * N);
+            _y_local.resize(2 * N);
+        }
+
+        template <typename Real>
         void DDHCore<Real>::solve(int d0, int d1, const double *x, double *y, bool zero_y, const Real *lambda, Real *update) const
         {
             ensure_plan();
-            int err;
-            if constexpr (std::is_same_v<Real, float>)
-                err = cuddh_hip_ddh_apply_f32(plan, d0, d1, x, y, zero_y ? 1 : 0, lambda, update, stream());
-            else
-                err = cuddh_hip_ddh_apply_f64(plan, d0, d1, x, y, zero_y ? 1 : 0, lambda, update, stream());
-            check_hip(err, "DDH local solves");
+            auto run = [&](const double *xx, double *yy, bool zy)
+            {
+                int err;
+                if constexpr (std::is_same_v<Real, float>)
+                    err = cuddh_hip_ddh_apply_f32(plan, d0, d1, xx, yy, zy ? 1 : 0, lambda, update, stream());
+                else
+                    err = cuddh_hip_ddh_apply_f64(plan, d0, d1, xx, yy, zy ? 1 : 0, lambda, update, stream());
+                check_hip(err, "DDH local solves");
+            };
+            if (!y)
+            {
+                run(x, nullptr, false);
+                return;
+            }
+            // With a solution output the reference adds every subdomain's weighted values into y with atomics
+            // (source/DDH.cpp:298-307), in whatever order the blocks finish.  Here the subdomains write into their own entries
+            // (identity numbering) and a second kernel sums the copies of each global dof in increasing subdomain order:
+            // postprocess is bitwise reproducible and equals a serial loop over the subdomains.
+            ensure_assembly();
+            const int N = mx_dof * n_domains;
+            const int *d_loc = _gI_local.device_read();
+            double *xl = nullptr;
+            if (x)
+            {
+                xl = _x_local.device_write();
+                check_hip(cuddh_hip_gather_f64(N, _gI.device_read(), x, xl, stream()), "DDH forcing gather");
+                check_hip(cuddh_hip_gather_f64(N, _gI.device_read(), x + g_ndof, xl + N, stream()), "DDH forcing gather");
+            }
+            double *yl = _y_local.device_write();
+            check_hip(cuddh_hip_ddh_plan_set_vector_layout(plan, d_loc, N), "DDH local layout");
+            try
+            {
+                run(xl, yl, true);
+            }
+            catch (...)
+            {
+                cuddh_hip_ddh_plan_set_vector_layout(plan, nullptr, 0);
+                throw;
+            }
+            check_hip(cuddh_hip_ddh_plan_set_vector_layout(plan, nullptr, 0), "DDH layout reset");
+            const int *off = _csr_off.device_read(), *src = _csr_src.device_read();
+            check_hip(cuddh_hip_csr_sum_f64(g_ndof, off, src, yl, y, zero_y ? 0 : 1, stream()), "DDH solution assembly");
+            check_hip(cuddh_hip_csr_sum_f64(g_ndof, off, src, yl + N, y + g_ndof, zero_y ? 0 : 1, stream()), "DDH solution assembly");
         }
 
         template class DDHCore<float>;

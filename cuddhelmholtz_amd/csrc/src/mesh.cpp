@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cstdint>
 #include <limits>
+#include <new>
 
 namespace cuddh
 {
@@ -130,17 +131,18 @@ namespace cuddh
 
         detail::PhaseTimer timer;
         Mesh2D mesh;
-        mesh._nodes.resize(static_cast<std::size_t>(npx) * npy);
-        mesh._elements.resize(static_cast<std::size_t>(nx) * ny);
+        // raw slots: every node, element and edge is constructed in place by the row loops below, exactly once
+        Node *nodes = mesh._nodes.claim(static_cast<std::size_t>(npx) * npy);
+        QuadElement *elements = mesh._elements.claim(static_cast<std::size_t>(nx) * ny);
         const std::size_t row0 = static_cast<std::size_t>(3) * nx + 1, rowk = static_cast<std::size_t>(2) * nx + 1;
-        mesh._edges.resize(row0 + rowk * (ny - 1));
+        StraightEdge *edges = mesh._edges.claim(row0 + rowk * (ny - 1));
 
         detail::parallel_for(static_cast<std::size_t>(npy), [&](std::size_t j0, std::size_t j1, int)
         {
             for (int j = static_cast<int>(j0); j < static_cast<int>(j1); ++j)
                 for (int i = 0; i < npx; ++i)
                 {
-                    Node &nd = mesh._nodes[static_cast<std::size_t>(i) + static_cast<std::size_t>(npx) * j];
+                    Node &nd = *new (nodes + static_cast<std::size_t>(i) + static_cast<std::size_t>(npx) * j) Node();
                     nd.id = i + npx * j;
                     nd.x[0] = vx(i);
                     nd.x[1] = vy(j);
@@ -178,7 +180,7 @@ namespace cuddh
                     q.nodes[1] = se;
                     q.nodes[2] = ne;
                     q.nodes[3] = nw;
-                    mesh._elements[el] = q;
+                    new (elements + el) QuadElement(q);
 
                     std::size_t id = base + static_cast<std::size_t>(per) * i + (i > 0 ? 1 : 0);
                     auto put = [&](int side, int v0, int v1, const double *x0, const double *x1, int el1, int side1)
@@ -198,7 +200,7 @@ namespace cuddh
                         }
                         else
                             e.type = FaceType::BOUNDARY;
-                        mesh._edges[id++] = e;
+                        new (edges + id++) StraightEdge(e);
                     };
                     if (j == 0)
                         put(0, sw, se, X + 0, X + 2, -1, -1);                                  // bottom: c0 -> c1

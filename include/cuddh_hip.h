@@ -98,6 +98,9 @@ int cuddh_hip_reciprocal_f64(int n, double *x, void *stream);
 int cuddh_hip_gather_f64(int n, const int *proj, const double *x, double *y, void *stream);      /* y[i]  = x[proj[i]] */
 int cuddh_hip_scatter_add_f64(int n, const int *proj, const double *x, double *y, void *stream); /* y[proj[i]] += x[i] */
 int cuddh_hip_zero_indexed_f64(int n, const int *proj, double *x, void *stream);                 /* x[proj[i]] = 0 */
+/* y[r] = (accumulate ? y[r] : 0) + sum of x[src[k]], k in [off[r], off[r+1]), added in list order (fixed-order replacement of
+ * the atomic adds of source/DDH.cpp:303,306) */
+int cuddh_hip_csr_sum_f64(int n_rows, const int *off, const int *src, const double *x, double *y, int accumulate, void *stream);
 /* Trace exchange of the multi-GPU DDH path (new: the reference is single-GPU).  A slot t stands for entries t and n_half + t
  * of a trace vector v (lambda and mu halves).  pack: buf[i] = v[slot[i]], buf[n + i] = v[n_half + slot[i]] and, with
  * clear != 0, those entries of v are zeroed (they belong to the receiving rank); unpack: the inverse copy. */
@@ -247,6 +250,12 @@ int cuddh_hip_ddh_plan_create(cuddh_ddh_plan **plan, const cuddh_ddh_desc *desc,
 int cuddh_hip_ddh_plan_destroy(cuddh_ddh_plan *plan);
 /* which kernel the plan resolved to (1..7) */
 int cuddh_hip_ddh_plan_kernel(const cuddh_ddh_plan *plan);
+/* Numbering of the forcing x and the solution y of the NEXT apply calls: d_gI (mx_dof, n_domains) DEVICE replaces desc.gI and
+ * g_ndof replaces desc.g_ndof for x and y (NULL restores the descriptor's).  With the identity numbering
+ * gI(l, s) = l + mx_dof s every subdomain dof has its own entry, so the partition-of-unity contributions that source/DDH.cpp:298-307
+ * adds with atomics land in distinct places and can be summed per global dof in a FIXED order afterwards
+ * (cuddh_hip_csr_sum_f64): DDH::postprocess is then bitwise reproducible. */
+int cuddh_hip_ddh_plan_set_vector_layout(cuddh_ddh_plan *plan, const int *d_gI, int g_ndof);
 /* WaveHoltz iterations per local solve.  The reference hard-wires 5 (`constexpr int wh_maxit = 5`,
  * source/DDH.cpp:136) and that is the default; 0 restores it.  A verification knob: with more iterations the local
  * solves become exact and DDH converges to the Helmholtz system its transmission conditions imply

@@ -552,6 +552,16 @@ def test_ddh_fp64_entry_points(cuda, nx, nb, kernel):
     F.postprocess(lam, f, u)
     u_ref = O.postprocess(lam_h, fh)
     assert rel(u.cpu().numpy(), u_ref) < 1e-10
+    # the solution is assembled in a fixed order (no atomics, unlike source/DDH.cpp:303,306): bitwise reproducible, and the
+    # sharded form (two ranges accumulated one after the other) is bitwise the whole
+    u2 = torch.full_like(u, -3.0)
+    F.postprocess(lam, f, u2)
+    assert torch.equal(u, u2)
+    nd0 = F.info()["n_domains"]
+    u3 = torch.full_like(u, 7.0)
+    F.local_solution(0, nd0 // 2, lam, f, u3, True)
+    F.local_solution(nd0 // 2, nd0, lam, f, u3, False)
+    assert torch.equal(u, u3)
     # sharded entry points (multi-GPU path): two halves reproduce the whole
     nd = F.info()["n_domains"]
     upd = torch.zeros(n, dtype=torch.float64, device=cuda)
@@ -696,7 +706,7 @@ def test_sharded_ddh_single_rank_equals_ddh(cuda):
     u2 = torch.ones_like(u1)
     F.postprocess(b1, f, u1)
     sh.postprocess(b1, f, u2)
-    assert torch.allclose(u1, u2, rtol=1e-12, atol=1e-14)
+    assert torch.equal(u1, u2)  # fixed-order assembly of the solution
 
 
 def test_unpreconditioned_gmres_on_helmholtz_operator(cuda):
