@@ -135,6 +135,8 @@ _sig("cuddh_hip_operator_plan_create", ci, C.POINTER(vp), ci, ci, ci, ci, vp, vp
 _sig("cuddh_hip_operator_plan_apply", ci, vp, cd, ci, vp, vp, vp)
 _sig("cuddh_hip_ddh_geom_setup_f32", ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp)
 _sig("cuddh_hip_ddh_geom_setup_f64", ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp)
+_sig("cuddh_hip_ddh_geom_from_corners_f32", ci, ci, ci, vp, vp, vp, vp, vp, vp, vp)
+_sig("cuddh_hip_ddh_geom_from_corners_f64", ci, ci, ci, vp, vp, vp, vp, vp, vp, vp)
 _sig("cuddh_hip_ddh_plan_create", ci, C.POINTER(vp), C.POINTER(DdhDesc), ci, ci)
 _sig("cuddh_hip_ddh_plan_destroy", ci, vp)
 _sig("cuddh_hip_ddh_plan_kernel", ci, vp)

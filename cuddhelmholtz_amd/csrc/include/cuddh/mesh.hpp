@@ -120,7 +120,13 @@ namespace cuddh
             /// shape (2, n, n, n_elem)
             const double *physical_coordinates(MemorySpace m) const;
 
+            /// DEVICE inputs of the on-device evaluation, for kernels that evaluate the bilinear map themselves instead of
+            /// reading a table: corner coordinates (2, 4, n_elem), counter-clockwise, and the rule's n nodes
+            const double *corner_coordinates_device() const;
+            const double *rule_nodes_device() const;
+
         private:
+            void ensure_corners() const;
             /// first request on the DEVICE: evaluated there from the elements' corners (no host table, no upload)
             void on_device(host_device_dvec &out, int dim, int which) const;
 

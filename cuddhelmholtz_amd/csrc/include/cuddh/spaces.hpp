@@ -19,6 +19,8 @@
 #include "operator.hpp"
 #include "tensor.hpp"
 
+#include <mutex>
+
 namespace cuddh
 {
     class H1Space
@@ -34,10 +36,17 @@ namespace cuddh
         const Mesh2D &mesh() const { return _mesh; }
         const Basis &basis() const { return _basis; }
 
-        /// shape (2, ndof): collocation point of every dof
-        const_dmat_wrapper physical_coordinates(MemorySpace m) const { return reshape(_xy.read(m), 2, ndof); }
+        /// shape (2, ndof): collocation point of every dof.  Evaluated at the first request (the reference fills it in the
+        /// constructor, source/H1Space.cpp:108-126; the solvers never read it, the drivers do once, for their output).
+        const_dmat_wrapper physical_coordinates(MemorySpace m) const
+        {
+            std::call_once(_xy_once, [this] { build_collocation_points(); });
+            return reshape(_xy.read(m), 2, ndof);
+        }
 
     private:
+        void build_collocation_points() const;
+
         const int n_elem;
         const int n_basis;
         const Mesh2D &_mesh;
@@ -45,7 +54,8 @@ namespace cuddh
         int ndof;
 
         host_device_ivec _I;
-        host_device_dvec _xy;
+        mutable host_device_dvec _xy;
+        mutable std::once_flag _xy_once;
     };
 
     class FaceSpace

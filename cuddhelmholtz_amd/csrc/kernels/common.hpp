@@ -39,6 +39,18 @@ namespace cuddh_k
         return v;
     }
 
+    /// Jacobian [x_xi, y_xi, x_eta, y_eta] of the bilinear map of source/Element.cpp:5-36 at (s, e); c = (2, 4) corners,
+    /// counter-clockwise.  One definition for every kernel that needs it, so that all of them round alike.
+    __device__ inline void bilinear_jacobian(const double *__restrict__ c, double s, double e, double j4[4])
+    {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+        {
+            j4[a] = 0.25 * ((1 - e) * (c[2 + a] - c[0 + a]) + (1 + e) * (c[4 + a] - c[6 + a]));
+            j4[2 + a] = 0.25 * ((1 - s) * (c[6 + a] - c[0 + a]) + (1 + s) * (c[4 + a] - c[2 + a]));
+        }
+    }
+
     /// hardware floating point atomic add (global_atomic_add_f64 / _f32), no CAS loop
     __device__ inline void atomic_add(double *p, double v) { unsafeAtomicAdd(p, v); }
     __device__ inline void atomic_add(float *p, float v) { unsafeAtomicAdd(p, v); }

@@ -1202,7 +1202,8 @@ namespace
     template <typename Real>
     __global__ void __launch_bounds__(256) ddh_geom_kernel(long long total, int nodes, int nb, int mx_elems, const int *__restrict__ n_elems,
                                                           const int *__restrict__ elems, const double *__restrict__ w,
-                                                          const double *__restrict__ J, Real *__restrict__ G)
+                                                          const double *__restrict__ J, const double *__restrict__ corners,
+                                                          const double *__restrict__ pts, Real *__restrict__ G)
     {
         for (long long t = blockIdx.x * 256LL + threadIdx.x; t < total; t += gridDim.x * 256LL)
         {
@@ -1215,9 +1216,16 @@ namespace
                 continue;
             }
             const int g_el = elems[el + (size_t)mx_elems * s];
-            const double *Jp = J + 4 * ((size_t)i + nb * ((size_t)j + nb * (size_t)g_el));
             const double W = w[i] * w[j];
-            const double x_xi = Jp[0], y_xi = Jp[1], x_eta = Jp[2], y_eta = Jp[3];
+            double j4[4];
+            if (J)
+            {
+                const double *Jp = J + 4 * ((size_t)i + nb * ((size_t)j + nb * (size_t)g_el));
+                j4[0] = Jp[0], j4[1] = Jp[1], j4[2] = Jp[2], j4[3] = Jp[3];
+            }
+            else // straight from the element's corners: no (2, 2, nb, nb, g_elem) table
+                bilinear_jacobian(corners + 8 * (size_t)g_el, pts[i], pts[j], j4);
+            const double x_xi = j4[0], y_xi = j4[1], x_eta = j4[2], y_eta = j4[3];
             const double det = x_xi * y_eta - x_eta * y_xi;
             g[0] = static_cast<Real>(W * (y_eta * y_eta + x_eta * x_eta) / det);
             g[1] = static_cast<Real>(-W * (y_xi * y_eta + x_xi * x_eta) / det);
@@ -1226,15 +1234,15 @@ namespace
     }
 
     template <typename Real>
-    int geom_setup(int n_domains, int mx_elems, int nb, const int *n_elems, const int *elems, const double *w, const double *J, Real *G,
-                   void *stream)
+    int geom_setup(int n_domains, int mx_elems, int nb, const int *n_elems, const int *elems, const double *w, const double *J,
+                   const double *corners, const double *pts, Real *G, void *stream)
     {
         const int nodes = nb * nb * mx_elems;
         const long long total = (long long)nodes * n_domains;
         if (total <= 0)
             return 0;
         hipLaunchKernelGGL((ddh_geom_kernel<Real>), dim3(stream_grid(total, 256)), dim3(256), 0, as_stream(stream), total, nodes, nb,
-                           mx_elems, n_elems, elems, w, J, G);
+                           mx_elems, n_elems, elems, w, J, corners, pts, G);
         return launch_status();
     }
 
@@ -1521,14 +1529,30 @@ extern "C"
                                      const double *w, const double *J, float *G, void *stream)
     {
         (void)g_elem;
-        return geom_setup<float>(n_domains, mx_elems, nb, n_elems, elems, w, J, G, stream);
+        return geom_setup<float>(n_domains, mx_elems, nb, n_elems, elems, w, J, nullptr, nullptr, G, stream);
     }
 
     int cuddh_hip_ddh_geom_setup_f64(int n_domains, int mx_elems, int g_elem, int nb, const int *n_elems, const int *elems,
                                      const double *w, const double *J, double *G, void *stream)
     {
         (void)g_elem;
-        return geom_setup<double>(n_domains, mx_elems, nb, n_elems, elems, w, J, G, stream);
+        return geom_setup<double>(n_domains, mx_elems, nb, n_elems, elems, w, J, nullptr, nullptr, G, stream);
+    }
+
+    int cuddh_hip_ddh_geom_from_corners_f32(int n_domains, int mx_elems, int nb, const int *n_elems, const int *elems, const double *w,
+                                            const double *points, const double *corners, float *G, void *stream)
+    {
+        if (!corners || !points)
+            return static_cast<int>(hipErrorInvalidValue);
+        return geom_setup<float>(n_domains, mx_elems, nb, n_elems, elems, w, nullptr, corners, points, G, stream);
+    }
+
+    int cuddh_hip_ddh_geom_from_corners_f64(int n_domains, int mx_elems, int nb, const int *n_elems, const int *elems, const double *w,
+                                            const double *points, const double *corners, double *G, void *stream)
+    {
+        if (!corners || !points)
+            return static_cast<int>(hipErrorInvalidValue);
+        return geom_setup<double>(n_domains, mx_elems, nb, n_elems, elems, w, nullptr, corners, points, G, stream);
     }
 
     int cuddh_hip_ddh_plan_create(cuddh_ddh_plan **out, const cuddh_ddh_desc *desc, int is_f64, int kernel)

@@ -45,12 +45,7 @@ namespace
             const double s = q[loc % n], e = q[loc / n];
             const double *c = corners + 8 * el; // (2, 4): corners counter-clockwise
             double j4[4];
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-            {
-                j4[a] = 0.25 * ((1 - e) * (c[2 + a] - c[0 + a]) + (1 + e) * (c[4 + a] - c[6 + a]));
-                j4[2 + a] = 0.25 * ((1 - s) * (c[6 + a] - c[0 + a]) + (1 + s) * (c[4 + a] - c[2 + a]));
-            }
+            bilinear_jacobian(c, s, e, j4);
             if (J)
             {
                 J[4 * t] = j4[0];

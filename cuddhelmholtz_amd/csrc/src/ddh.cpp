@@ -22,14 +22,14 @@ namespace cuddh
         namespace
         {
             template <typename Real>
-            void geom_setup(int n_domains, int mx_elems, int g_elem, int nb, const int *n_elems, const int *elems,
-                            const double *w, const double *J, Real *G)
+            void geom_setup(int n_domains, int mx_elems, int nb, const int *n_elems, const int *elems, const double *w,
+                            const double *points, const double *corners, Real *G)
             {
                 int err;
                 if constexpr (std::is_same_v<Real, float>)
-                    err = cuddh_hip_ddh_geom_setup_f32(n_domains, mx_elems, g_elem, nb, n_elems, elems, w, J, G, stream());
+                    err = cuddh_hip_ddh_geom_from_corners_f32(n_domains, mx_elems, nb, n_elems, elems, w, points, corners, G, stream());
                 else
-                    err = cuddh_hip_ddh_geom_setup_f64(n_domains, mx_elems, g_elem, nb, n_elems, elems, w, J, G, stream());
+                    err = cuddh_hip_ddh_geom_from_corners_f64(n_domains, mx_elems, nb, n_elems, elems, w, points, corners, G, stream());
                 check_hip(err, "DDH geometric factors");
             }
         } // namespace
@@ -316,12 +316,17 @@ namespace cuddh
             double *hw = w.host_write();
             for (int i = 0; i < nb; ++i)
                 hw[i] = q.w(i);
-            const double *d_J = fem_mesh->element_metrics(q).jacobians(MemorySpace::DEVICE);
+            // (the reference reads the tabulated Jacobians, source/DDH.cpp:530-537; here the kernel evaluates the bilinear map from
+            // the corners: the 0.5 GB table at 1024^2 is neither built nor kept)
+            const auto &metrics = fem_mesh->element_metrics(q);
+            const double *d_corners = metrics.corner_coordinates_device();
+            check_hip(cuddh_hip_stream_sync(stream()), "DDH element corners");
+            timer.lap("plan: element corners to the device");
             _g_tensor.resize(3 * nb * nb * mx_elem_per_dom * n_domains);
-            geom_setup<Real>(n_domains, mx_elem_per_dom, g_elem, nb, efem->n_elems(MemorySpace::DEVICE),
-                             efem->elements(MemorySpace::DEVICE), w.device_read(), d_J, _g_tensor.device_write());
+            geom_setup<Real>(n_domains, mx_elem_per_dom, nb, efem->n_elems(MemorySpace::DEVICE), efem->elements(MemorySpace::DEVICE),
+                             w.device_read(), metrics.rule_nodes_device(), d_corners, _g_tensor.device_write());
             check_hip(cuddh_hip_stream_sync(stream()), "DDH geometric factors");
-            timer.lap("plan: Jacobians + geometric factors");
+            timer.lap("plan: geometric factors");
 
             cuddh_ddh_desc d;
             d.g_ndof = g_ndof;

@@ -283,7 +283,7 @@ namespace cuddh
         }
     } // namespace
 
-    void Mesh2D::ElementMetricCollection::on_device(host_device_dvec &out, int dim, int which) const
+    void Mesh2D::ElementMetricCollection::ensure_corners() const
     {
         const int m = quad.size(), nel = mesh.n_elem();
         if (corners.size() == 0)
@@ -307,6 +307,24 @@ namespace cuddh
             for (int i = 0; i < m; ++i)
                 p[i] = quad.x(i);
         }
+    }
+
+    const double *Mesh2D::ElementMetricCollection::corner_coordinates_device() const
+    {
+        ensure_corners();
+        return corners.device_read();
+    }
+
+    const double *Mesh2D::ElementMetricCollection::rule_nodes_device() const
+    {
+        ensure_corners();
+        return points.device_read();
+    }
+
+    void Mesh2D::ElementMetricCollection::on_device(host_device_dvec &out, int dim, int which) const
+    {
+        const int m = quad.size(), nel = mesh.n_elem();
+        ensure_corners();
         out.resize(dim * m * m * nel);
         double *d = out.device_write();
         detail::check_hip(cuddh_hip_element_metrics(nel, m, corners.device_read(), points.device_read(), which == 0 ? d : nullptr,

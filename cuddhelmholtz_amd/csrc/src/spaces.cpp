@@ -109,6 +109,13 @@ namespace cuddh
         });
 
         timer.lap("H1Space: numbering");
+    }
+
+    void H1Space::build_collocation_points() const
+    {
+        detail::PhaseTimer timer;
+        const int nb = n_basis;
+        const int *I = _I.host_read();
         // collocation points: the reference overwrites a shared dof's point element after element, the highest element wins
         // (source/H1Space.cpp:108-126).  In parallel: each range of elements first stamps the dofs it touches with its range
         // number (highest wins), then writes only the dofs it won, in element order -- the same winner as the serial loop.

@@ -198,6 +198,14 @@ int cuddh_hip_ddh_geom_setup_f32(int n_domains, int mx_elems, int g_elem, int nb
 int cuddh_hip_ddh_geom_setup_f64(int n_domains, int mx_elems, int g_elem, int nb, const int *n_elems, const int *elems,
                                  const double *w, const double *J, double *G, void *stream);
 
+/* The same factors straight from the elements' corners ((2, 4, g_elem), counter-clockwise) and the rule's nodes `points`
+ * (nb): the bilinear Jacobian of source/Element.cpp:5-36 is evaluated in the kernel (with the arithmetic of
+ * cuddh_hip_element_metrics), so the (2,2,nb,nb,g_elem) table of source/Mesh2D.cpp:173-227 is never built. */
+int cuddh_hip_ddh_geom_from_corners_f32(int n_domains, int mx_elems, int nb, const int *n_elems, const int *elems, const double *w,
+                                        const double *points, const double *corners, float *G, void *stream);
+int cuddh_hip_ddh_geom_from_corners_f64(int n_domains, int mx_elems, int nb, const int *n_elems, const int *elems, const double *w,
+                                        const double *points, const double *corners, double *G, void *stream);
+
 /* The arrays DDH holds after its constructor (include/DDH.hpp:55-83,
  * source/DDH.cpp:425-608), in the reference's own layouts.  `real` is float for
  * *_f32 and double for *_f64.  All DEVICE pointers. */

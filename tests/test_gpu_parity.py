@@ -520,6 +520,56 @@ def ddh_case(nx, nb):
     return omega, d, h_a, f
 
 
+@pytest.mark.parametrize("real", ["f64", "f32"])
+def test_ddh_geometric_factors_table_and_corner_forms(cuda, real):
+    """source/DDH.cpp:15-58 on an irregular mesh (every element its own Jacobian; three 'subdomains' of unequal element
+    counts): cuddh_hip_ddh_geom_setup_* reading the tabulated Jacobians, cuddh_hip_ddh_geom_from_corners_* evaluating
+    the bilinear map itself (the form DDH's constructor uses), and the oracle."""
+    import ctypes as C
+
+    import torch
+
+    from cuddhelmholtz_amd import _native as N
+
+    lib = N.lib
+    _, om = meshes("unstructured")
+    nb = 4
+    d = oracle.Discretization(om, nb)
+    nel = om.n_elem
+    J, _, _ = d.metrics(d.gll_x)
+    rng = np.random.default_rng(5)
+    counts = np.array([40, 17, 33], dtype=np.int32)
+    mx = int(counts.max())
+    elems = np.zeros((mx, 3), dtype=np.int32, order="F")
+    for s in range(3):
+        elems[:counts[s], s] = rng.choice(nel, counts[s], replace=False)
+    npt = np.float64 if real == "f64" else np.float32
+    Gref = np.zeros((3, nb * nb * mx, 3), dtype=npt, order="F")
+    fn = oracle.lib().orc_ddh_geom_f64 if real == "f64" else oracle.lib().orc_ddh_geom_f32
+    fn(C.c_int(3), C.c_int(mx), C.c_int(nb), oracle._p(counts), oracle._p(elems), oracle._p(d.gll_w), oracle._p(J), oracle._p(Gref))
+
+    tt = torch.float64 if real == "f64" else torch.float32
+    dev = lambda a: to_dev(torch, np.asarray(a).reshape(-1, order="F"), cuda)  # noqa: E731
+    p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    dc, de, dw, dq = dev(counts), dev(elems), dev(d.gll_w), dev(d.gll_x)
+    dcorn = dev(np.ascontiguousarray(d.corners, dtype=np.float64))
+    dJ = torch.zeros(4 * nb * nb * nel, dtype=torch.float64, device=cuda)
+    assert lib.cuddh_hip_element_metrics(nel, nb, p(dcorn), p(dq), p(dJ), None, None, st) == 0
+    assert rel(dJ.cpu().numpy(), J.reshape(-1, order="F")) < 1e-14
+    G_tab = torch.full((Gref.size,), 7.0, dtype=tt, device=cuda)
+    G_cor = torch.full((Gref.size,), 7.0, dtype=tt, device=cuda)
+    sfx = "f64" if real == "f64" else "f32"
+    assert getattr(lib, "cuddh_hip_ddh_geom_setup_" + sfx)(3, mx, nel, nb, p(dc), p(de), p(dw), p(dJ), p(G_tab), st) == 0
+    assert getattr(lib, "cuddh_hip_ddh_geom_from_corners_" + sfx)(3, mx, nb, p(dc), p(de), p(dw), p(dq), p(dcorn), p(G_cor), st) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(G_tab, G_cor)  # one definition of the bilinear Jacobian: the two forms round alike
+    assert rel(G_cor.cpu().numpy(), Gref.reshape(-1, order="F")) < (1e-13 if real == "f64" else 2e-7)
+    pad = G_cor.cpu().numpy().reshape(Gref.shape, order="F")[:, nb * nb * 17:, 1]
+    assert not pad.any()  # entries past a subdomain's element count are zero, as in the reference
+    assert getattr(lib, "cuddh_hip_ddh_geom_from_corners_" + sfx)(3, mx, nb, p(dc), p(de), p(dw), p(dq), None, p(G_cor), st) != 0
+
+
 @pytest.mark.parametrize("nx,nb,kernel", [(8, 4, 1), (8, 4, 2), (16, 4, 2), (8, 8, 1), (8, 8, 6), (6, 8, 6), (10, 3, 1), (9, 5, 1), (16, 2, 1)])
 def test_ddh_fp64_entry_points(cuda, nx, nb, kernel):
     import torch
