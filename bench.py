@@ -112,6 +112,9 @@ def main() -> None:
     ap.add_argument("--sharded-apply", action="store_true",
                     help="N > 1: also time the partitioned global Helmholtz apply (element partition + halo exchanges, "
                          "cuddhelmholtz_amd.dist.ShardedHelmholtz) and report its aggregate rate as `roofline_sharded`")
+    ap.add_argument("--overlap", action="store_true",
+                    help="N > 1: split schedule (boundary subdomains first, on a second stream with issue priority, exchange behind "
+                         "them, interior meanwhile); default is exchange-after-solve")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-gmres-call", action="store_true", help="skip the real gmres() call timed beside the step loop")
@@ -196,7 +199,8 @@ def main() -> None:
     if world > 1 and args.exchange == "neighbour":
         ok, sh_nb, b_nb = 0.0, None, None
         try:
-            sh_nb = NeighbourShardedDDH(F, nd, rank, world, device=dev, host_staging=staged)
+            sh_nb = NeighbourShardedDDH(F, nd, rank, world, device=dev, host_staging=staged, overlap=args.overlap,
+                                        set_stream=cd.use_torch_stream)
             b_nb = torch.zeros_like(b)
             sh_nb.rhs(f, b_nb)
             # traces are copied, not summed: the assembled vector must be bitwise the all-reduce result
@@ -328,6 +332,7 @@ def main() -> None:
                          "neighbour": f"{world} contiguous subdomain ranges, trace vectors partitioned by slot ownership, grouped RCCL "
                                       f"send/recv of {sum(i.numel() for i in getattr(sh, 'send_idx', {}).values()) * 4 / 1024:.0f} KiB to "
                                       f"{len(getattr(sh, 'send_idx', {}))} neighbour rank(s) per step (rank 0), all-reduce of each inner product"}[exchange]
+                        + (", split schedule (boundary subdomains first with issue priority, exchange behind them)" if (args.overlap and exchange == "neighbour") else "")
                         + (f" [{exchange_note}]" if exchange_note else ""),
             "setup_seconds": round(t_constructors, 3),  # Mesh2D + H1Space + load vector / coefficient + DDH constructor + plan
             "rhs_and_exchange_check_seconds": round(t_setup - t_constructors, 3),  # DDH::rhs (one pass of local solves) [+ N > 1 start-up check]

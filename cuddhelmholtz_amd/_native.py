@@ -141,6 +141,9 @@ _sig("cuddh_hip_ddh_plan_create", ci, C.POINTER(vp), C.POINTER(DdhDesc), ci, ci)
 _sig("cuddh_hip_ddh_plan_destroy", ci, vp)
 _sig("cuddh_hip_ddh_plan_kernel", ci, vp)
 _sig("cuddh_hip_ddh_plan_set_wh_iters", ci, vp, ci)
+_sig("cuddh_hip_ddh_plan_set_wave_priority", ci, vp, ci)
+_sig("cuddh_hip_ddh_apply_list_f32", ci, vp, vp, ci, vp, vp, ci, vp, vp, vp)
+_sig("cuddh_hip_ddh_apply_list_f64", ci, vp, vp, ci, vp, vp, ci, vp, vp, vp)
 _sig("cuddh_hip_ddh_plan_set_vector_layout", ci, vp, vp, ci)
 _sig("cuddh_hip_ddh_apply_f32", ci, vp, ci, ci, vp, vp, ci, vp, vp, vp)
 _sig("cuddh_hip_ddh_apply_f64", ci, vp, ci, ci, vp, vp, ci, vp, vp, vp)
@@ -207,6 +210,7 @@ _sig("cuddh_ddh_destroy", None, vp)
 _sig("cuddh_ddh_size", ci, vp)
 _sig("cuddh_ddh_info", ci, vp, vp, vp)
 _sig("cuddh_ddh_set_wh_iters", ci, vp, ci)
+_sig("cuddh_ddh_set_wave_priority", ci, vp, ci)
 
 
 class MultiGpuResult(C.Structure):
@@ -220,6 +224,7 @@ _sig("cuddh_ddh_rhs", ci, vp, vp, vp)
 _sig("cuddh_ddh_postprocess", ci, vp, vp, vp, vp)
 _sig("cuddh_ddh_action", ci, vp, vp, vp)
 _sig("cuddh_ddh_local_traces", ci, vp, ci, ci, vp, vp, vp)
+_sig("cuddh_ddh_local_traces_listed", ci, vp, vp, ci, vp, vp, vp)
 _sig("cuddh_ddh_local_solution", ci, vp, ci, ci, vp, vp, vp, ci)
 _sig("cuddh_ddh_table", C.c_longlong, vp, cp, vp, ci)
 _sig("cuddh_gmres_f64", ci, ci, vp, vp, vp, vp, ci, ci, cd, ci, cd, C.POINTER(SolverResult), vp, vp)

@@ -31,7 +31,7 @@ def _ptr(t, dtype=None, numel=None, what="tensor"):
     if dtype is not None:
         import torch
 
-        want = {"f64": torch.float64, "f32": torch.float32}.get(dtype, dtype)
+        want = {"f64": torch.float64, "f32": torch.float32, "i32": torch.int32}.get(dtype, dtype)
         if t.dtype != want:
             raise ValueError(f"{what}: expected dtype {want}, got {t.dtype}")
     if numel is not None and t.numel() < numel:
@@ -422,6 +422,10 @@ class DDH:
         """Verification knob: WaveHoltz iterations per local solve (reference: 5, source/DDH.cpp:136)."""
         N.check_capi(lib.cuddh_ddh_set_wh_iters(self._h, int(n)), "DDH.set_wh_iters")
 
+    def set_wave_priority(self, high: bool):
+        """The local solves launched next take issue priority over other resident wavefronts (s_setprio); results unchanged."""
+        N.check_capi(lib.cuddh_ddh_set_wave_priority(self._h, 1 if high else 0), "DDH.set_wave_priority")
+
     def table(self, name: str) -> np.ndarray:
         n = lib.cuddh_ddh_table(self._h, name.encode(), None, 1)
         if n < 0:
@@ -445,6 +449,12 @@ class DDH:
     def local_traces(self, d0, d1, f, lam, update):
         N.check_capi(lib.cuddh_ddh_local_traces(self._h, d0, d1, _ptr(f, "f64", 2 * self.fem.size(), "f"), _ptr(lam, self.trace_dtype, self.size(), "lambda"),
                                                  _ptr(update, self.trace_dtype, self.size(), "update")), "DDH.local_traces")
+
+    def local_traces_listed(self, domains, f, lam, update):
+        """local_traces for the subdomains listed in `domains` (int32 device tensor, distinct ids), one launch"""
+        N.check_capi(lib.cuddh_ddh_local_traces_listed(self._h, _ptr(domains, "i32", domains.numel(), "domains"), int(domains.numel()),
+                                                        _ptr(f, "f64", 2 * self.fem.size(), "f"), _ptr(lam, self.trace_dtype, self.size(), "lambda"),
+                                                        _ptr(update, self.trace_dtype, self.size(), "update")), "DDH.local_traces_listed")
 
     def local_solution(self, d0, d1, lam, f, u, zero_u=True):
         N.check_capi(lib.cuddh_ddh_local_solution(self._h, d0, d1, _ptr(lam, self.trace_dtype, self.size(), "lambda"), _ptr(f, "f64", 2 * self.fem.size(), "f"),

@@ -41,11 +41,16 @@ namespace cuddh
             /// WaveHoltz iterations per local solve; the reference hard-wires 5 (source/DDH.cpp:136), the default.
             /// Verification knob (tests/test_ddh_physics.py), see cuddh_hip_ddh_plan_set_wh_iters.
             void set_waveholtz_iterations(int n) const;
+            /// The wavefronts of the following solve() calls take issue priority over other resident work (s_setprio): for the
+            /// multi-GPU schedule that runs the subdomains other ranks wait for beside the rest (cuddh_hip_ddh_plan_set_wave_priority).
+            void set_wave_priority(bool high) const;
             const EnsembleSpace &ensemble() const { return *efem; }
 
             /// runs the local solves of subdomains [dom_begin, dom_end)
             void solve(int dom_begin, int dom_end, const double *x, double *y, bool zero_y, const Real *lambda,
                        Real *update) const;
+            /// traces only, for the n subdomains listed in d_domains (DEVICE), one launch (cuddh_hip_ddh_apply_list_*)
+            void solve_listed(const int *d_domains, int n, const double *x, const Real *lambda, Real *update) const;
 
             // host copies of the constructor's tables (tests compare them with the oracle)
             const host_device_ivec &table_B() const { return _Bf; }

@@ -33,6 +33,7 @@ struct cuddh_ddh_plan
     int g_ndof_override = 0;
     float *Aop = nullptr; // kernel 5: element stiffness matrix as MFMA A operands, [4 k-steps][64 lanes]
     float *Sep = nullptr; // kernel 7: [Ax | Ay | beta | gamma] of the separable nb = 8 sweep
+    int wave_priority = 0; // cuddh_hip_ddh_plan_set_wave_priority
 };
 
 namespace
@@ -44,6 +45,7 @@ namespace
     {
         int g_ndof, n_lambda, nt, mx_dof, mx_fdof, nodes, dom_begin, dom_end;
         int wh_iters; // 5 unless a verification run changed it (cuddh_hip_ddh_plan_set_wh_iters)
+        int prio;     // != 0: these wavefronts take issue priority over others on their SIMD (cuddh_hip_ddh_plan_set_wave_priority)
         Real omega, dt;
         const int *s_dof, *s_fdof, *B, *gI, *sI;
         const Real *G, *m, *gmi, *a, *H;
@@ -51,7 +53,24 @@ namespace
         double *y;
         const Real *lambda;
         Real *update;
+        const int *dom_list; // null: positions [dom_begin, dom_end) ARE the subdomains; else subdomain = dom_list[position]
     };
+
+    template <typename Real>
+    __device__ inline int domain_at(const DdhArgs<Real> &A, int position)
+    {
+        return A.dom_list ? A.dom_list[position] : position;
+    }
+
+    // Issue priority of the calling wavefront (s_setprio).  All wavefronts of one rank's local solves are resident at once and
+    // advance at the same rate, so a launch of the few subdomains whose traces other ranks wait for finishes no earlier than
+    // the launch of all the others it shares the SIMDs with (profiles/r02/overlap_timeline.txt) -- unless its wavefronts are
+    // issued first whenever they are ready.
+    __device__ inline void raise_priority(int prio)
+    {
+        if (prio)
+            __builtin_amdgcn_s_setprio(3);
+    }
 
     // ---------------------------------------------------------------- DPP helpers
     template <int CTRL>
@@ -257,9 +276,11 @@ namespace
                                                           const Real *__restrict__ cs, const Real *__restrict__ sn)
     {
         const int lane = threadIdx.x & 63;
-        const int s = A.dom_begin + blockIdx.x * 4 + (threadIdx.x >> 6);
-        if (s >= A.dom_end)
+        const int position = A.dom_begin + blockIdx.x * 4 + (threadIdx.x >> 6);
+        if (position >= A.dom_end)
             return; // wave-uniform: the kernel has no barriers
+        const int s = domain_at(A, position);
+        raise_priority(A.prio);
 
         const int k = lane & 3, el = lane >> 2, ex = el & 3, ey = el >> 2;
         const int fdof = A.s_fdof[s];
@@ -638,13 +659,14 @@ namespace
                                                            const Real *__restrict__ cs, const Real *__restrict__ sn,
                                                            const Real *__restrict__ Sep)
     {
+        raise_priority(A.prio);
         const int lane = threadIdx.x & 63;
         const int s_first = A.dom_begin + 2 * (blockIdx.x * 4 + (threadIdx.x >> 6));
         if (s_first >= A.dom_end)
             return; // wave-uniform: the kernel has no barriers
         const int sub = lane >> 5;
         const bool valid = s_first + sub < A.dom_end;
-        const int s = valid ? s_first + sub : s_first; // a missing second subdomain recomputes the first, writes nothing
+        const int s = domain_at(A, valid ? s_first + sub : s_first); // a missing second subdomain recomputes the first, writes nothing
 
         const int k = lane & 7, el = (lane >> 3) & 3, ex = el & 1, ey = el >> 1;
         const int fdof = A.s_fdof[s];
@@ -830,9 +852,11 @@ namespace
     {
         typedef float f4 __attribute__((ext_vector_type(4)));
         const int lane = threadIdx.x & 63;
-        const int s = A.dom_begin + blockIdx.x * 4 + (threadIdx.x >> 6);
-        if (s >= A.dom_end)
+        const int position = A.dom_begin + blockIdx.x * 4 + (threadIdx.x >> 6);
+        if (position >= A.dom_end)
             return; // wave-uniform, no barriers in this kernel
+        const int s = domain_at(A, position);
+        raise_priority(A.prio);
 
         const int k = lane >> 4, el = lane & 15, ex = el & 3, ey = el >> 2;
         const int fdof = A.s_fdof[s];
@@ -1025,9 +1049,10 @@ namespace
     __global__ void __launch_bounds__(256) ddh_block_kernel(DdhArgs<Real> A, const Real *__restrict__ Dmat, const Real *__restrict__ filt,
                                                            const Real *__restrict__ cs, const Real *__restrict__ sn)
     {
+        raise_priority(A.prio);
         const int T = A.nodes; // == blockDim.x
         const int tid = threadIdx.x;
-        const int s = A.dom_begin + blockIdx.x;
+        const int s = domain_at(A, A.dom_begin + blockIdx.x);
 
         extern __shared__ double lds_raw[];
         Real *s_p = reinterpret_cast<Real *>(lds_raw); // [T] field, indexed by subdomain dof
@@ -1398,13 +1423,13 @@ namespace
     }
 
     template <typename Real>
-    int apply(const cuddh_ddh_plan *plan, int dom_begin, int dom_end, const double *x, double *y, int zero_y, const Real *lambda,
+    int apply(const cuddh_ddh_plan *plan, const int *dom_list, int dom_begin, int dom_end, const double *x, double *y, int zero_y, const Real *lambda,
               Real *update, void *stream)
     {
         if (!plan || plan->is_f64 != (sizeof(Real) == 8 ? 1 : 0))
             return static_cast<int>(hipErrorInvalidValue);
         const cuddh_ddh_desc &d = plan->d;
-        if (dom_begin < 0 || dom_end > d.n_domains || dom_begin > dom_end)
+        if (dom_begin < 0 || (!dom_list && dom_end > d.n_domains) || dom_begin > dom_end)
             return static_cast<int>(hipErrorInvalidValue);
         hipStream_t st = as_stream(stream);
         const int g_ndof = plan->gI_override ? plan->g_ndof_override : d.g_ndof;
@@ -1423,11 +1448,13 @@ namespace
         A.n_lambda = d.n_lambda;
         A.nt = d.nt;
         A.wh_iters = plan->wh_iters;
+        A.prio = plan->wave_priority;
         A.mx_dof = d.mx_dof;
         A.mx_fdof = d.mx_fdof;
         A.nodes = plan->nodes;
         A.dom_begin = dom_begin;
         A.dom_end = dom_end;
+        A.dom_list = dom_list;
         A.omega = static_cast<Real>(d.omega);
         A.dt = static_cast<Real>(d.dt);
         A.s_dof = d.s_dof;
@@ -1665,6 +1692,14 @@ extern "C"
         return 0;
     }
 
+    int cuddh_hip_ddh_plan_set_wave_priority(cuddh_ddh_plan *plan, int high)
+    {
+        if (!plan)
+            return static_cast<int>(hipErrorInvalidValue);
+        plan->wave_priority = high ? 1 : 0;
+        return 0;
+    }
+
     int cuddh_hip_ddh_plan_set_wh_iters(cuddh_ddh_plan *plan, int wh_iters)
     {
         if (!plan || wh_iters < 0)
@@ -1676,12 +1711,28 @@ extern "C"
     int cuddh_hip_ddh_apply_f32(const cuddh_ddh_plan *plan, int dom_begin, int dom_end, const double *x, double *y, int zero_y,
                                 const float *lambda, float *update, void *stream)
     {
-        return apply<float>(plan, dom_begin, dom_end, x, y, zero_y, lambda, update, stream);
+        return apply<float>(plan, nullptr, dom_begin, dom_end, x, y, zero_y, lambda, update, stream);
+    }
+
+    int cuddh_hip_ddh_apply_list_f32(const cuddh_ddh_plan *plan, const int *d_domains, int n, const double *x, double *y, int zero_y,
+                                     const float *lambda, float *update, void *stream)
+    {
+        if (!d_domains && n > 0)
+            return static_cast<int>(hipErrorInvalidValue);
+        return apply<float>(plan, d_domains, 0, n, x, y, zero_y, lambda, update, stream);
+    }
+
+    int cuddh_hip_ddh_apply_list_f64(const cuddh_ddh_plan *plan, const int *d_domains, int n, const double *x, double *y, int zero_y,
+                                     const double *lambda, double *update, void *stream)
+    {
+        if (!d_domains && n > 0)
+            return static_cast<int>(hipErrorInvalidValue);
+        return apply<double>(plan, d_domains, 0, n, x, y, zero_y, lambda, update, stream);
     }
 
     int cuddh_hip_ddh_apply_f64(const cuddh_ddh_plan *plan, int dom_begin, int dom_end, const double *x, double *y, int zero_y,
                                 const double *lambda, double *update, void *stream)
     {
-        return apply<double>(plan, dom_begin, dom_end, x, y, zero_y, lambda, update, stream);
+        return apply<double>(plan, nullptr, dom_begin, dom_end, x, y, zero_y, lambda, update, stream);
     }
 }

@@ -675,6 +675,17 @@ extern "C"
                 h->f32->internals().set_waveholtz_iterations(n);
         });
     }
+    int cuddh_ddh_set_wave_priority(void *d, int high)
+    {
+        return guarded([&]
+        {
+            auto *h = static_cast<DdhHandle *>(d);
+            if (h->is64())
+                h->f64->internals().set_wave_priority(high != 0);
+            else
+                h->f32->internals().set_wave_priority(high != 0);
+        });
+    }
     int cuddh_ddh_rhs(void *d, const double *f, void *b)
     {
         return guarded([&]
@@ -717,6 +728,17 @@ extern "C"
                 h->f64->local_traces(d0, d1, f, static_cast<const double *>(lambda), static_cast<double *>(update));
             else
                 h->f32->local_traces(d0, d1, f, static_cast<const float *>(lambda), static_cast<float *>(update));
+        });
+    }
+    int cuddh_ddh_local_traces_listed(void *d, const int *d_domains, int n, const double *f, const void *lambda, void *update)
+    {
+        return guarded([&]
+        {
+            auto *h = static_cast<DdhHandle *>(d);
+            if (h->is64())
+                h->f64->internals().solve_listed(d_domains, n, f, static_cast<const double *>(lambda), static_cast<double *>(update));
+            else
+                h->f32->internals().solve_listed(d_domains, n, f, static_cast<const float *>(lambda), static_cast<float *>(update));
         });
     }
     int cuddh_ddh_local_solution(void *d, int d0, int d1, const void *lambda, const double *f, double *u, int zero_u)

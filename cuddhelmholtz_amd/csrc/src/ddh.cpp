@@ -375,6 +375,13 @@ namespace cuddh
         }
 
         template <typename Real>
+        void DDHCore<Real>::set_wave_priority(bool high) const
+        {
+            ensure_plan();
+            check_hip(cuddh_hip_ddh_plan_set_wave_priority(plan, high ? 1 : 0), "DDH wave priority");
+        }
+
+        template <typename Real>
         void DDHCore<Real>::ensure_assembly() const
         {
             if (_csr_off.size() > 0)
@@ -454,6 +461,18 @@ namespace cuddh
             const int *off = _csr_off.device_read(), *src = _csr_src.device_read();
             check_hip(cuddh_hip_csr_sum_f64(g_ndof, off, src, yl, y, zero_y ? 0 : 1, stream()), "DDH solution assembly");
             check_hip(cuddh_hip_csr_sum_f64(g_ndof, off, src, yl + N, y + g_ndof, zero_y ? 0 : 1, stream()), "DDH solution assembly");
+        }
+
+        template <typename Real>
+        void DDHCore<Real>::solve_listed(const int *d_domains, int n, const double *x, const Real *lambda, Real *update) const
+        {
+            ensure_plan();
+            int err;
+            if constexpr (std::is_same_v<Real, float>)
+                err = cuddh_hip_ddh_apply_list_f32(plan, d_domains, n, x, nullptr, 0, lambda, update, stream());
+            else
+                err = cuddh_hip_ddh_apply_list_f64(plan, d_domains, n, x, nullptr, 0, lambda, update, stream());
+            check_hip(err, "DDH local solves (listed subdomains)");
         }
 
         template class DDHCore<float>;

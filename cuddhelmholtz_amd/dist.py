@@ -216,6 +216,7 @@ class NeighbourShardedDDH:
         self.recv_idx = {s: as_idx(a) for s, a in self.ex.recv_slots.items()}
         self.owned_idx = as_idx(self.ex.owned_slots)
         self._side = torch.cuda.Stream(self.device) if (overlap and self.device.type == "cuda") else None
+        self._boundary_list = None  # device list of the subdomains other ranks wait for (split schedule)
 
     # ---- communication
     def reduce(self, t) -> None:
@@ -283,12 +284,31 @@ class NeighbourShardedDDH:
             return
         import torch
 
+        # All wavefronts of a rank's local solves are resident at once and advance at the same rate: launched beside the
+        # interior, a boundary range finishes WITH it (and a second boundary range queued behind the first then runs alone:
+        # profiles/r02/overlap_timeline.txt, 44 + 8 ms).  So the boundary wavefronts take issue priority (s_setprio): they
+        # finish first, the exchange starts, and the interior fills the rest of the step.
+        # ONE launch for all boundary ranges, so that boundary + interior wavefronts together are exactly the residents of the
+        # unsplit launch (queued one behind the other, the pieces leave SIMDs with one subdomain more than the rest: 49 ms).
+        prio = getattr(self.engine, "set_wave_priority", None)
+        listed = getattr(self.engine, "local_traces_listed", None)
+        if listed and self._boundary_list is None:
+            ids = [s for a, b in self.ex.boundary_ranges for s in range(a, b)]
+            self._boundary_list = torch.tensor(ids, dtype=torch.int32, device=self.device)
         main = torch.cuda.current_stream(self.device)
         self._side.wait_stream(main)
         with torch.cuda.stream(self._side):
             self.set_stream()
-            for a, b in self.ex.boundary_ranges:
-                self.engine.local_traces(a, b, f, lam, out)
+            if prio:
+                prio(True)
+            if listed:
+                if self._boundary_list.numel():
+                    listed(self._boundary_list, f, lam, out)
+            else:
+                for a, b in self.ex.boundary_ranges:
+                    self.engine.local_traces(a, b, f, lam, out)
+            if prio:
+                prio(False)
             pending = self._start_exchange(out)
         self.set_stream()
         for a, b in self.ex.interior_ranges:

@@ -131,11 +131,15 @@ int cuddh_trace_exchange_query(const int *h_B, int n_domains, int mx_fdof, int n
                                int *h_out);
 /* verification knob: WaveHoltz iterations per local solve (reference: 5, source/DDH.cpp:136; 0 restores it) */
 int cuddh_ddh_set_wh_iters(void *ddh, int n);
+/* the local solves launched next take issue priority on the device (cuddh_hip_ddh_plan_set_wave_priority); 0 restores */
+int cuddh_ddh_set_wave_priority(void *ddh, int high);
 /* traces are float for f64 == 0 and double otherwise */
 int cuddh_ddh_rhs(void *ddh, const double *f, void *b);
 int cuddh_ddh_postprocess(void *ddh, const void *lambda, const double *f, double *u);
 int cuddh_ddh_action(void *ddh, const void *x, void *y);
 int cuddh_ddh_local_traces(void *ddh, int d0, int d1, const double *f, const void *lambda, void *update);
+/* the same for n listed subdomains (d_domains: DEVICE ints, distinct, in range) in one launch */
+int cuddh_ddh_local_traces_listed(void *ddh, const int *d_domains, int n, const double *f, const void *lambda, void *update);
 int cuddh_ddh_local_solution(void *ddh, int d0, int d1, const void *lambda, const double *f, double *u, int zero_u);
 /* HOST copies of the constructor's tables: name in {"B","gI","sI"} (int) or
  * {"D","G","m","gmi","a","H","filter","cs","sn"} (float / double by f64).  count_only != 0: just return the length. */

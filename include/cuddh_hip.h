@@ -264,6 +264,10 @@ int cuddh_hip_ddh_plan_kernel(const cuddh_ddh_plan *plan);
  * adds with atomics land in distinct places and can be summed per global dof in a FIXED order afterwards
  * (cuddh_hip_csr_sum_f64): DDH::postprocess is then bitwise reproducible. */
 int cuddh_hip_ddh_plan_set_vector_layout(cuddh_ddh_plan *plan, const int *d_gI, int g_ndof);
+/* Issue priority of the wavefronts of the NEXT apply calls (s_setprio 3 when high != 0; 0 restores the default).  For the
+ * multi-GPU schedule that solves the subdomains feeding other ranks on a second stream: with equal priority they finish
+ * together with everything else resident on the device (profiles/r02/overlap_timeline.txt).  Results are unaffected. */
+int cuddh_hip_ddh_plan_set_wave_priority(cuddh_ddh_plan *plan, int high);
 /* WaveHoltz iterations per local solve.  The reference hard-wires 5 (`constexpr int wh_maxit = 5`,
  * source/DDH.cpp:136) and that is the default; 0 restores it.  A verification knob: with more iterations the local
  * solves become exact and DDH converges to the Helmholtz system its transmission conditions imply
@@ -281,6 +285,13 @@ int cuddh_hip_ddh_apply_f32(const cuddh_ddh_plan *plan, int dom_begin, int dom_e
                             int zero_y, const float *lambda, float *update, void *stream);
 int cuddh_hip_ddh_apply_f64(const cuddh_ddh_plan *plan, int dom_begin, int dom_end, const double *x, double *y,
                             int zero_y, const double *lambda, double *update, void *stream);
+/* The same for the n subdomains listed in d_domains (DEVICE, each in [0, n_domains), no duplicates: the caller's contract) in
+ * ONE launch -- the subdomains of a rank whose traces other ranks wait for are not a contiguous range (two block rows of a
+ * strip, the rim of a 2-D rank grid), and launching them piecewise leaves pieces running alone on an almost idle device. */
+int cuddh_hip_ddh_apply_list_f32(const cuddh_ddh_plan *plan, const int *d_domains, int n, const double *x, double *y, int zero_y,
+                                 const float *lambda, float *update, void *stream);
+int cuddh_hip_ddh_apply_list_f64(const cuddh_ddh_plan *plan, const int *d_domains, int n, const double *x, double *y, int zero_y,
+                                 const double *lambda, double *update, void *stream);
 
 #ifdef __cplusplus
 }

@@ -657,6 +657,22 @@ def test_ddh_fp32_reference_precision(cuda, nx, nb, kernel):
     F.local_traces(0, 3, f, None, part)
     F.local_traces(3, nd, f, None, part)
     assert torch.equal(part, b)
+    # listed subdomains in one launch (the split multi-GPU schedule: non-contiguous, any order, odd counts)
+    rng = np.random.default_rng(nx + kernel)
+    perm = rng.permutation(nd).astype(np.int32)
+    cut = max(1, nd // 3) | 1
+    listed = torch.zeros_like(b)
+    for ids in (perm[:cut], perm[cut:]):
+        if len(ids):
+            F.local_traces_listed(to_dev(torch, ids, cuda), f, None, listed)
+    assert torch.equal(listed, b)
+    # the multi-GPU schedule's issue priority (s_setprio) changes when wavefronts are issued, never what they compute
+    F.set_wave_priority(True)
+    hi = torch.zeros_like(b)
+    F.local_traces(0, 3, f, None, hi)
+    F.set_wave_priority(False)
+    F.local_traces(3, nd, f, None, hi)
+    assert torch.equal(hi, b)
 
 
 @pytest.mark.parametrize("kernel", [1, 2])

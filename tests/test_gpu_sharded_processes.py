@@ -58,15 +58,18 @@ def test_two_processes_neighbour_exchange(cuda, tmp_path, precision, overlap):
         assert boundary and interior
 
 
-def test_bench_two_rank_rehearsal(cuda):
+@pytest.mark.parametrize("split", [False, True])
+def test_bench_two_rank_rehearsal(cuda, split):
     """bench.py's N > 1 code path (partition, neighbour exchange chosen after its start-up cross-check against the
     all-reduce assembly, reduced inner products, max-over-ranks timing, one JSON line from rank 0) with two ranks
-    sharing the GPU over gloo.  The printed rate is not a measurement."""
+    sharing the GPU over gloo; with and without the split schedule (boundary subdomains as one listed launch with issue
+    priority on a second stream -- the start-up cross-check then compares THAT assembly bitwise with the all-reduce one).
+    The printed rate is not a measurement."""
     import json
 
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(free_port()), str(ROOT / "bench.py"), "--gpus", "2", "--rehearse-gloo", "--nx", "64", "--steps", "3",
-           "--warmup", "1", "--no-roofline"]
+           "--warmup", "1", "--no-roofline"] + (["--overlap"] if split else [])
     r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout + r.stderr
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -74,6 +77,7 @@ def test_bench_two_rank_rehearsal(cuda):
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 3 and out["scaling"] == "strong" and out["config"]["finite"]
     assert "partitioned by slot ownership" in out["config"]["sharding"] and "fell back" not in out["config"]["sharding"]
+    assert ("split schedule" in out["config"]["sharding"]) == split
     assert "cpu_baseline" not in out  # N = 1 only
 
 
