@@ -32,6 +32,13 @@ def declared_symbols() -> list[str]:
 
 
 def _load() -> C.CDLL:
+    # developer knob for same-box A/B runs of two builds of THIS library (profiles/tools/build_variant.py): a file name under
+    # cuddhelmholtz_amd/lib/.  Never a fallback: a missing file raises like the default one.
+    global LIB_PATH
+    import os
+
+    if os.environ.get("CUDDH_AMD_LIBRARY_VARIANT"):
+        LIB_PATH = LIB_PATH.parent / os.environ["CUDDH_AMD_LIBRARY_VARIANT"]
     if not LIB_PATH.exists():
         raise NativeLibraryMissing(
             f"{LIB_PATH} is missing: build it with `python -m cuddhelmholtz_amd.build` "

@@ -72,6 +72,7 @@ struct cuddh_helmholtz_plan
     int streaming = 0; // metric loads carry the non-temporal hint (plans larger than the infinity cache)
     int lane_form = 0; // fused apply through helm_lane_kernel (one element per lane, both components)
     int prefetch = 0;  // lane form with the whole patch's metric block requested up front (one wavefront per SIMD)
+    int pair_mass = 0; // helm_patch_kernel, general layout, n_basis 3: two mass slices per round trip (CUDDH_HELM_PAIR_MASS=0 for A/B)
     int pair_layout = 0; // metric slices stored as [pairs of values][64 lanes][2] (+ one single row): 16-byte loads (lane form)
     unsigned long long *stamps = nullptr; // CUDDH_HELM_STAMPS=1: [n_patches][8] phase time stamps (100 MHz) of the lane form
     size_t bytes_affine = 0; // algorithmic bytes of the affine form (0 when neither metric array is uniform)
@@ -129,13 +130,18 @@ namespace
         const double *x;
         double *y, *part;
         unsigned long long *stamps; // diagnostic: phase time stamps per patch, or null
+        int pair_mass;              // helm_patch_kernel: two mass slices per round trip
     };
 
     // Variants measured and dropped: software-pipelined slice loads, slices split between the half-waves
     // and exchanged with ds_bpermute, three role-specialised wavefronts per patch, touch-prefetch of the metric block.
     // UG: the stiffness metric is the same in every element and comes from the uniform table GU (scalar loads)
     // PEK elements per patch: 32 = one wavefront, 64 = two wavefronts sharing the LDS copy of a larger patch (fewer border dofs)
-    template <int NB, int NQS, int NQM, bool NT, bool UG, int PEK>
+    // MODE 0: one slice per dependent round trip; 1: the mass phase takes two slices per round trip (n_basis 3: 256^2 19.5 ->
+    // 18.0 us, 512^2 unchanged; at n_basis 5 it spills 35 registers at 3 wavefronts per SIMD: 421 -> 549 us, not used there.  A
+    // double-buffered chain at 2 wavefronts per SIMD for n_basis 5 -- next slice requested before the current one is computed
+    // -- compiled to 256 registers + 13 spilled with the requests sunk below the arithmetic again: 431 -> 450 us, removed)
+    template <int NB, int NQS, int NQM, bool NT, bool UG, int PEK, int MODE = 0>
     __global__ void __launch_bounds__(2 * PEK, (NB >= 5 ? (UG ? 2 : 3) : ((NB == 4 && !UG) ? 3 : 4))) helm_patch_kernel(HelmArgs A, const double *__restrict__ PS, const double *__restrict__ DS,
                                                            const double *__restrict__ PM, const double *__restrict__ PF,
                                                            const double *__restrict__ GU)
@@ -185,6 +191,7 @@ namespace
         // (same-box A/B, 256^2 ... 1024^2 and the irregular mesh); the affine form loses 30 % that way and stays at 2.
         // n_basis 4, general layout: 153 VGPRs at 3 waves/SIMD (no spills, first slice prefetched) measured faster than
         // 128 VGPRs with 8 spilled at 4 waves/SIMD (1024^2: 402 vs 420 us; irregular 0.49 M quads: 187 vs 222 us)
+        constexpr bool PAIRM = MODE == 1;
         constexpr bool PRE = !UG && NB <= 4;
         double g_first[3 * NQS];
         if constexpr (PRE)
@@ -378,12 +385,36 @@ namespace
                 load_stiff(q, g);
                 stiff_slice(q, g);
             }
-#pragma unroll 1
-            for (int q = 0; q < NQM; ++q)
+            // two mass slices per round trip where their 2 NQM weights need no more registers than the 3 NQS metric values of a
+            // stiffness slice, dead by now (n_basis 5: 18 = 18; n_basis 3: 12 = 12): NQS + ceil(NQM / 2) dependent round trips
+            // instead of NQS + NQM
+            if constexpr (PAIRM)
             {
-                double am[NQM];
-                load_mass(q, am);
-                mass_slice(q, am);
+#pragma unroll 1
+                for (int q = 0; q + 1 < NQM; q += 2)
+                {
+                    double am0[NQM], am1[NQM];
+                    load_mass(q, am0);
+                    load_mass(q + 1, am1);
+                    mass_slice(q, am0);
+                    mass_slice(q + 1, am1);
+                }
+                if constexpr (NQM % 2 == 1)
+                {
+                    double am[NQM];
+                    load_mass(NQM - 1, am);
+                    mass_slice(NQM - 1, am);
+                }
+            }
+            else
+            {
+#pragma unroll 1
+                for (int q = 0; q < NQM; ++q)
+                {
+                    double am[NQM];
+                    load_mass(q, am);
+                    mass_slice(q, am);
+                }
             }
         }
 
@@ -1133,10 +1164,22 @@ namespace
     {
         const size_t lds = (size_t)4 * p->max_loc * sizeof(double);
         const dim3 grid(8 * A.xcd_chunk), block(2 * PEK);
+        // general layout, 2 NQM <= 3 NQS (n_basis 3 and 5): the mass phase takes two slices per round trip (PM)
+        constexpr bool CAN_PAIR = 2 * NQM <= 3 * NQS && NB <= 4;
         if (p->Gu && p->streaming)
             hipLaunchKernelGGL((helm_patch_kernel<NB, NQS, NQM, true, true, PEK>), grid, block, lds, st, A, p->PS, p->DS, p->PM, p->PF, p->Gu);
         else if (p->Gu)
             hipLaunchKernelGGL((helm_patch_kernel<NB, NQS, NQM, false, true, PEK>), grid, block, lds, st, A, p->PS, p->DS, p->PM, p->PF, p->Gu);
+        else if (CAN_PAIR && A.pair_mass)
+        {
+            if constexpr (CAN_PAIR)
+            {
+                if (p->streaming)
+                    hipLaunchKernelGGL((helm_patch_kernel<NB, NQS, NQM, true, false, PEK, 1>), grid, block, lds, st, A, p->PS, p->DS, p->PM, p->PF, p->Gu);
+                else
+                    hipLaunchKernelGGL((helm_patch_kernel<NB, NQS, NQM, false, false, PEK, 1>), grid, block, lds, st, A, p->PS, p->DS, p->PM, p->PF, p->Gu);
+            }
+        }
         else if (p->streaming)
             hipLaunchKernelGGL((helm_patch_kernel<NB, NQS, NQM, true, false, PEK>), grid, block, lds, st, A, p->PS, p->DS, p->PM, p->PF, p->Gu);
         else
@@ -1218,6 +1261,7 @@ namespace
         A.y = y;
         A.part = p->part;
         A.stamps = p->stamps;
+        A.pair_mass = p->pair_mass;
         return A;
     }
 
@@ -1747,6 +1791,11 @@ namespace
         static_assert(NB >= 6 && NB <= 8 && NQS <= 16 && NQM <= 16, "xi-indices k = g + 4 s with s < 2");
         constexpr int NN = NB * NB, NP = (NN + 1) / 2, PEM = 16;
         constexpr int JS = (NQS + 3) / 4, JM = (NQM + 3) / 4;
+        // stiffness / mass slices per dependent round trip.  Same-box A/B of four builds (profiles/r02/mfma_grouping_ab.txt): at
+        // n_basis 7 two / four per trip fit the 168 registers of 3 wavefronts per SIMD (161) and gain 6-8 % (irregular
+        // 121,856-quad mesh 190 -> 179 us, 384^2 230 -> 214 us); n_basis 6 (128-register cap, 21 spilled; 3 wavefronts per SIMD
+        // without spills: no better) and n_basis 8 (18 spilled) lose 5 %, four / six per trip at 2 wavefronts per SIMD loses 15 %
+        constexpr int GS = NB == 7 ? 2 : 1, GM = NB == 7 ? 4 : 1;
         extern __shared__ double lds[];
         const int patch = (blockIdx.x & 7) * A.xcd_chunk + (blockIdx.x >> 3);
         if (patch >= A.n_patches)
@@ -1838,23 +1887,35 @@ namespace
                     AbP[rb][sp] = ok ? PS[q + NQS * k] : 0.0;
                 }
             const double *Gb = Gm + (size_t)patch * gm_stride + e;
+            // GS slices travel together (a slice is 3 JS doubles per lane, 3 KB per wavefront); the fence keeps the group's loads
+            // ahead of its arithmetic in the generated code
 #pragma unroll 1
-            for (int r = 0; r < NQS; ++r)
+            for (int r0 = 0; r0 < NQS; r0 += GS)
             {
-                double ga[JS], gb[JS], gc[JS];
+                double gaG[GS][JS], gbG[GS][JS], gcG[GS][JS];
 #pragma unroll
-                for (int j = 0; j < JS; ++j)
-                {
-                    const int q = 4 * j + g;
-                    const bool ok = q < NQS;
-                    const size_t o = (((size_t)r * 3) * NQS + (ok ? q : 0)) * PEM;
-                    ga[j] = ok ? Gb[o] : 0.0;
-                    gb[j] = ok ? Gb[o + (size_t)NQS * PEM] : 0.0;
-                    gc[j] = ok ? Gb[o + (size_t)2 * NQS * PEM] : 0.0;
-                }
+                for (int gi = 0; gi < GS; ++gi)
 #pragma unroll
-                for (int c = 0; c < 1; ++c)
+                    for (int j = 0; j < JS; ++j)
+                    {
+                        const int q = 4 * j + g, rr = min(r0 + gi, NQS - 1);
+                        const bool ok = q < NQS;
+                        const size_t o = (((size_t)rr * 3) * NQS + (ok ? q : 0)) * PEM;
+                        gaG[gi][j] = ok ? Gb[o] : 0.0;
+                        gbG[gi][j] = ok ? Gb[o + (size_t)NQS * PEM] : 0.0;
+                        gcG[gi][j] = ok ? Gb[o + (size_t)2 * NQS * PEM] : 0.0;
+                    }
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int gi = 0; gi < GS; ++gi)
                 {
+                    const int r = r0 + gi;
+                    if (r >= NQS)
+                        break;
+                    const double(&ga)[JS] = gaG[gi], (&gb)[JS] = gbG[gi], (&gc)[JS] = gcG[gi];
+                    constexpr int c = 0;
+                    {
                     double pl[2], dl[2];
 #pragma unroll
                     for (int s = 0; s < 2; ++s)
@@ -1897,6 +1958,7 @@ namespace
 #pragma unroll
                         for (int l = 0; l < NB; ++l)
                             OUT[c][s][l] += PS[r + NQS * l] * W0[s] + DS[r + NQS * l] * W1[s];
+                    }
                 }
             }
         }
@@ -1922,18 +1984,31 @@ namespace
                 }
             const double *ab = Am + (size_t)patch * am_stride + e;
 #pragma unroll 1
-            for (int r = 0; r < NQM; ++r)
+            for (int r0 = 0; r0 < NQM; r0 += GM)
             {
-                double am[JM];
+                double amG[GM][JM];
 #pragma unroll
-                for (int j = 0; j < JM; ++j)
-                {
-                    const int q = 4 * j + g;
-                    am[j] = q < NQM ? w2 * ab[((size_t)r * NQM + q) * PEM] : 0.0;
-                }
+                for (int gi = 0; gi < GM; ++gi)
 #pragma unroll
-                for (int c = 0; c < 1; ++c)
+                    for (int j = 0; j < JM; ++j)
+                    {
+                        const int q = 4 * j + g, rr = min(r0 + gi, NQM - 1);
+                        amG[gi][j] = q < NQM ? ab[((size_t)rr * NQM + q) * PEM] : 0.0;
+                    }
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int gi = 0; gi < GM; ++gi)
                 {
+                    const int r = r0 + gi;
+                    if (r >= NQM)
+                        break;
+                    double am[JM];
+#pragma unroll
+                    for (int j = 0; j < JM; ++j)
+                        am[j] = w2 * amG[gi][j];
+                    constexpr int c = 0;
+                    {
                     double pl[2];
 #pragma unroll
                     for (int s = 0; s < 2; ++s)
@@ -1962,6 +2037,7 @@ namespace
 #pragma unroll
                         for (int l = 0; l < NB; ++l)
                             OUT[c][s][l] += PM[r + NQM * l] * W[s];
+                    }
                 }
             }
         }
@@ -2517,6 +2593,9 @@ extern "C"
             // than the slice-by-slice chain at two wavefronts per SIMD (1024^2, n_basis 4: 434-442 vs 373-376 us), although
             // the metric stream alone runs at 6.46 TB/s that way -- see the comment at the kernel.  CUDDH_HELM_PRE=1 selects it
             // for A/B runs; tests keep it correct.
+            (*out)->pair_mass = nb == 3 && !(*out)->Gu && !(*out)->lane_form;
+            if (const char *e = std::getenv("CUDDH_HELM_PAIR_MASS"))
+                (*out)->pair_mass = (*out)->pair_mass && std::atoi(e) != 0;
             (*out)->prefetch = 0;
             if (const char *e = std::getenv("CUDDH_HELM_PRE"))
                 (*out)->prefetch = (*out)->lane_form && std::atoi(e) != 0;
@@ -2662,7 +2741,8 @@ extern "C"
         else if (fused && p->nb <= 4 && p->pe == 64 && p->lane_form)
             std::snprintf(buf, cap, "helm_lane_kernel<%d,%d,%d,NT=%d,UG=%d%s> pe=64", p->nb, p->nqS, p->nqM, nt, p->Gu ? 1 : 0, p->prefetch ? ",PRE=1" : "");
         else if (fused)
-            std::snprintf(buf, cap, "helm_patch_kernel<%d,%d,%d,NT=%d,UG=%d,PEK=%d> pe=%d", p->nb, p->nqS, p->nqM, nt, p->Gu ? 1 : 0, p->pe, p->pe);
+            std::snprintf(buf, cap, "helm_patch_kernel<%d,%d,%d,NT=%d,UG=%d,PEK=%d%s> pe=%d", p->nb, p->nqS, p->nqM, nt, p->Gu ? 1 : 0, p->pe,
+                          p->pair_mass ? ",MODE=1" : "", p->pe);
         else if (p->Gm || p->Am)
             std::snprintf(buf, cap, "op_mfma_kernel<%d,%d,%d> pe=16 affine=%d", p->nb, nq, kind, (kind == 0 ? p->gm_stride : p->am_stride) == 0 ? 1 : 0);
         else

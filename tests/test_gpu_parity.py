@@ -386,7 +386,12 @@ def test_patch_sizes_agree(cuda, kind, nx, nb, monkeypatch):
     got, seen = {}, set()
     # "lane0": helm_lane_kernel (n_basis <= 4; chosen by size otherwise), the slice-by-slice chain large plans run by default;
     # "lane": the same with the whole patch's metric block requested up front (CUDDH_HELM_PRE=1, one wavefront per SIMD)
-    for pe in ("32", "64", "lane", "lane0"):
+    # n_basis 3, general layout, helm_patch_kernel: the mass phase takes two slices per round trip (MODE=1) unless
+    # CUDDH_HELM_PAIR_MASS=0 ("32m0" / "64m0": the one-slice form)
+    for pe in ("32", "64", "lane", "lane0") + (("32m0", "64m0") if nb == 3 else ()):
+        pair_mass = not pe.endswith("m0")
+        monkeypatch.setenv("CUDDH_HELM_PAIR_MASS", "1" if pair_mass else "0")
+        pe = pe[:2] if pe.endswith("m0") else pe
         for affine in ("1", "0"):
             for nt in ("0", "1"):
                 if pe.startswith("lane"):
@@ -425,7 +430,8 @@ def test_patch_sizes_agree(cuda, kind, nx, nb, monkeypatch):
                     # forced sizes apply to n_basis <= 4; affine plans are 64-element ones unless forced; a lane request that
                     # does not apply (affine n_basis 3, 4; n_basis 5) leaves the default size
                     hpe = (int(pe) if not lane_like else (64 if ug else 32)) if nb <= 4 else 32
-                    want = f"helm_patch_kernel<{nb},{nqS},{nqM},NT={nt},UG={ug},PEK={hpe}> pe={hpe}"
+                    mode = ",MODE=1" if (nb == 3 and not ug and pair_mass) else ""
+                    want = f"helm_patch_kernel<{nb},{nqS},{nqM},NT={nt},UG={ug},PEK={hpe}{mode}> pe={hpe}"
                 assert A.kernel() == want, (A.kernel(), want)
                 seen.add(A.kernel())
                 assert rel(yS.cpu().numpy(), refS) < 1e-12 and rel(yM.cpu().numpy(), refM) < 1e-12
@@ -434,8 +440,8 @@ def test_patch_sizes_agree(cuda, kind, nx, nb, monkeypatch):
                 yS2 = to_dev(torch, refS, cuda).clone()
                 cd.StiffnessMatrix(fem).action(-1.0, x[: d.ndof], yS2)
                 assert float(yS2.abs().max()) < 1e-11 * float(np.abs(refS).max())
-                got[(pe, affine, nt)] = (yS.cpu().numpy(), yM.cpu().numpy(), y.cpu().numpy())
-    base = got[("32", "0", "0")]
+                got[(pe, affine, nt, pair_mass)] = (yS.cpu().numpy(), yM.cpu().numpy(), y.cpu().numpy())
+    base = got[("32", "0", "0", True)]
     for key, val in got.items():
         for a, b in zip(val, base):
             assert rel(a, b) < 1e-13, key
@@ -444,6 +450,8 @@ def test_patch_sizes_agree(cuda, kind, nx, nb, monkeypatch):
         assert f"helm_lane_kernel<{nb},{nqS},{nqM},NT=1,UG=0> pe=64" in seen
     if nb == 2 and kind == "structured":
         assert "helm_lane_kernel<2,3,5,NT=1,UG=1,PRE=1> pe=64" in seen
+    if nb == 3:
+        assert {"helm_patch_kernel<3,4,6,NT=1,UG=0,PEK=32,MODE=1> pe=32", "helm_patch_kernel<3,4,6,NT=1,UG=0,PEK=32> pe=32"} <= seen
 
 
 # ------------------------------------------------------------------ fused Helmholtz apply
