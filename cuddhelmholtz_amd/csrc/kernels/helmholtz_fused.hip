@@ -45,6 +45,7 @@ struct cuddh_helmholtz_plan
     int *dof_off = nullptr;   // [n_patches + 1] offsets into dof_list / slot_of
     int *dof_list = nullptr;  // global dof of every patch-local dof
     int *slot_of = nullptr;   // where a patch-local dof's result goes: its global dof (>= 0) if the patch owns it, else -(slot in `part`) - 1
+    int *own_count = nullptr; // [n_patches] local dofs [0, own_count) are owned (slot_of == dof_list there), the border dofs come last
     int *patch_nel = nullptr; // elements in the patch (32 except possibly the last)
     uint32_t *lidx = nullptr; // [n_patches][ceil(nb*nb/2)][32]: element nodes 2j, 2j+1 -> patch-local dofs, packed lo | hi << 16
     uint8_t *colour = nullptr; // [n_patches][32]
@@ -123,6 +124,7 @@ namespace
         int ndof, max_loc, ncol, nfcol, nqF, n_slots, n_patches, xcd_chunk;
         double omega;
         const int *dof_off, *dof_list, *slot_of, *patch_nel, *face_off, *face_id;
+        const int *own_count;
         const uint32_t *lidx;
         const uint16_t *face_lidx;
         const uint8_t *colour, *face_col;
@@ -651,13 +653,18 @@ namespace
         double aW[PRE ? NQM : 1][NQM];
 
         constexpr int ROWS = 10; // 640 dofs per pass: an 8x8-element patch of n_basis 4 (625) in one
-        // where the write-out sends the first 64 ROWS results: requested with the other indices at kernel entry
+        // Where the write-out sends its results (slot_of: the global dof of an owned local dof, -(slot) - 1 for a border dof).
+        // The plan numbers a patch's owned dofs first, so for the rows of 64 local dofs below j_own = own_count / 64 the
+        // destination IS the gather index and slot_of is not read at all: only its tail is (the rows holding border dofs),
+        // requested with the other indices at kernel entry when the registers allow (EARLY_DEST).
         const int *slot = A.slot_of + off;
+        const int j_own = A.own_count[patch] >> 6; // wave-uniform
         int dest0[ROWS];
         if constexpr (EARLY_DEST)
 #pragma unroll
             for (int j = 0; j < ROWS; ++j)
-                dest0[j] = slot[min(64 * j + lane, nloc - 1)];
+                if (j >= j_own)
+                    dest0[j] = slot[min(64 * j + lane, nloc - 1)];
         auto gather_pass = [&](int base, auto first)
         {
             constexpr bool WITH_METRIC = PRE && decltype(first)::value;
@@ -665,6 +672,11 @@ namespace
 #pragma unroll
             for (int j = 0; j < ROWS; ++j)
                 gi[j] = dofs[min(base + 64 * j + lane, nloc - 1)];
+            if constexpr (EARLY_DEST && decltype(first)::value)
+#pragma unroll
+                for (int j = 0; j < ROWS; ++j)
+                    if (j < j_own)
+                        dest0[j] = gi[j];
             if constexpr (WITH_METRIC)
             {
                 __builtin_amdgcn_sched_barrier(0);
@@ -863,10 +875,10 @@ namespace
             mass_slice(NQM - 1, am);
         }
 
-        if constexpr (!EARLY_DEST)
+        if constexpr (!EARLY_DEST) // (the owned rows re-read their gather indices: lines the gather brought on chip)
 #pragma unroll
             for (int j = 0; j < ROWS; ++j)
-                dest0[j] = slot[min(64 * j + lane, nloc - 1)];
+                dest0[j] = (j >= j_own ? slot : dofs)[min(64 * j + lane, nloc - 1)];
 
         if (A.stamps)
         {
@@ -1247,6 +1259,7 @@ namespace
         A.dof_off = p->dof_off;
         A.dof_list = p->dof_list;
         A.slot_of = p->slot_of;
+        A.own_count = p->own_count;
         A.patch_nel = p->patch_nel;
         A.face_off = p->face_off;
         A.face_id = p->face_id;
@@ -2234,7 +2247,7 @@ extern "C"
     {
         if (!p)
             return 0;
-        void *ptrs[] = {p->dof_off, p->dof_list, p->slot_of, p->patch_nel, p->lidx, p->colour, p->Gp, p->aMp, p->Gu, p->au, p->Gm, p->Am, p->face_off,
+        void *ptrs[] = {p->own_count, p->dof_off, p->dof_list, p->slot_of, p->patch_nel, p->lidx, p->colour, p->Gp, p->aMp, p->Gu, p->au, p->Gm, p->Am, p->face_off,
                         p->face_lidx, p->face_id, p->face_col, p->PS, p->DS, p->PM, p->PF, p->shared_dof, p->shared_off,
                         p->part, p->stamps};
         for (void *q : ptrs)
@@ -2326,13 +2339,58 @@ extern "C"
         std::vector<uint32_t> used, usedF;
         int max_loc = 0, ncol = 1, nfcol = 1;
         dof_list.reserve((size_t)n_elem * nn / 2);
+        // how many patches touch a dof (a dof touched by one patch is OWNED by it: its result goes straight to y)
+        for (int q = 0; q < n_patches; ++q)
+        {
+            const int nel = std::min(pe, n_elem - q * pe);
+            for (int le = 0; le < nel; ++le)
+            {
+                const int *gi = h_I + (size_t)nn * perm[q * pe + le];
+                for (int n = 0; n < nn; ++n)
+                    if (stamp[gi[n]] != q)
+                    {
+                        stamp[gi[n]] = q;
+                        touches[gi[n]]++;
+                    }
+            }
+        }
+        std::fill(stamp.begin(), stamp.end(), -1);
+        // Patch-local numbering: the owned dofs first, the border dofs (shared with other patches) last, each group in the
+        // order its dofs are first met.  The write-out of an owned dof then needs no destination entry -- it is the gather index
+        // -- so a kernel that knows own_count reads only the tail of the patch's slot_of segment (helm_lane_kernel does).
+        std::vector<int> own_count(n_patches), border_first;
         for (int q = 0; q < n_patches; ++q)
         {
             const int first = static_cast<int>(dof_list.size());
             dof_off[q] = first;
             const int nel = std::min(pe, n_elem - q * pe);
             patch_nel[q] = nel;
-            used.clear();
+            border_first.clear();
+            for (int le = 0; le < nel; ++le)
+            {
+                const int *gi = h_I + (size_t)nn * perm[q * pe + le];
+                for (int n = 0; n < nn; ++n)
+                {
+                    const int g = gi[n];
+                    if (stamp[g] == q)
+                        continue;
+                    stamp[g] = q;
+                    if (touches[g] > 1)
+                        border_first.push_back(g);
+                    else
+                    {
+                        loc[g] = static_cast<int>(dof_list.size()) - first;
+                        dof_list.push_back(g);
+                    }
+                }
+            }
+            own_count[q] = static_cast<int>(dof_list.size()) - first;
+            for (const int g : border_first)
+            {
+                loc[g] = static_cast<int>(dof_list.size()) - first;
+                dof_list.push_back(g);
+            }
+            used.assign(dof_list.size() - first, 0);
             for (int le = 0; le < nel; ++le)
             {
                 const int *gi = h_I + (size_t)nn * perm[q * pe + le];
@@ -2340,14 +2398,6 @@ extern "C"
                 for (int n = 0; n < nn; ++n)
                 {
                     const int g = gi[n];
-                    if (stamp[g] != q)
-                    {
-                        stamp[g] = q;
-                        loc[g] = static_cast<int>(dof_list.size()) - first;
-                        dof_list.push_back(g);
-                        touches[g]++;
-                        used.push_back(0);
-                    }
                     lidx[((size_t)q * np2 + n / 2) * pe + le] |= static_cast<uint32_t>(loc[g]) << (16 * (n & 1));
                     taken |= used[loc[g]];
                 }
@@ -2416,7 +2466,6 @@ extern "C"
         }
         p->n_shared = n_shared;
         p->n_slots = n_slots;
-
         // ---- upload
         int err = 0;
         auto ok = [&](int e)
@@ -2427,6 +2476,7 @@ extern "C"
         ok(upload(&p->dof_off, dof_off));
         ok(upload(&p->dof_list, dof_list));
         ok(upload(&p->slot_of, slot_of));
+        ok(upload(&p->own_count, own_count));
         ok(upload(&p->patch_nel, patch_nel));
         ok(upload(&p->lidx, lidx));
         ok(upload(&p->colour, colour));
@@ -2525,8 +2575,17 @@ extern "C"
         size_t exclusive = 0;
         for (int s : slot_of)
             exclusive += s >= 0;
-        p->bytes_actual = (size_t)nG * 8 + (size_t)nA * 8 + lidx.size() * 4 + colour.size() + dof_list.size() * (4 + 4 + 16) + // dof (gather), destination (write-out), x
-                         
+        // destination list of the write-out: one entry per local dof (slot_of); the lane form reads only the rows of 64 that hold
+        // border dofs
+        size_t dest_entries = dof_list.size();
+        if (p->pair_layout)
+        {
+            dest_entries = n_patches; // own_count
+            for (int q = 0; q < n_patches; ++q)
+                dest_entries += (dof_off[q + 1] - dof_off[q]) - (own_count[q] / 64) * 64;
+        }
+        const size_t dest_bytes = dest_entries * 4;
+        p->bytes_actual = (size_t)nG * 8 + (size_t)nA * 8 + lidx.size() * 4 + colour.size() + dof_list.size() * (4 + 16) + dest_bytes + // dof (gather), x
                           exclusive * 16 + (size_t)n_slots * (16 + 16) + (size_t)n_shared * (16 + 8) +
                           (size_t)n_faces * ((size_t)nqF * 8 + (size_t)nb * 2 + 5);
         if (p->Gu || p->au) // SURVEY 8d's "affine" figure: the uniform metric arrays are not traffic
