@@ -212,12 +212,16 @@ namespace
         // of the element phase, when the registers allow (EARLY), otherwise just before the colour phases
         constexpr bool EARLY = !UG && NB == 4;
         const int *slot = A.slot_of + off;
+        // rows of NTH local dofs below own_rows hold owned dofs only (the plan numbers those first): their destination is the
+        // gather index, so the destination list is read for the tail rows only (see op_patch_kernel)
+        const int own_rows = A.own_count[patch] / NTH;
         int dest0[ROWS];
         if constexpr (EARLY)
         {
 #pragma unroll
             for (int j = 0; j < ROWS; ++j)
-                dest0[j] = slot[min(NTH * j + lane, nloc - 1)];
+                if (j >= own_rows)
+                    dest0[j] = slot[min(NTH * j + lane, nloc - 1)];
         }
         for (int base = 0; base < nloc; base += NTH * ROWS)
         {
@@ -225,6 +229,12 @@ namespace
 #pragma unroll
             for (int j = 0; j < ROWS; ++j)
                 gi[j] = dofs[min(base + NTH * j + lane, nloc - 1)];
+            if constexpr (EARLY)
+                if (base == 0)
+#pragma unroll
+                    for (int j = 0; j < ROWS; ++j)
+                        if (j < own_rows)
+                            dest0[j] = gi[j];
             double xu[ROWS], xv[ROWS];
 #pragma unroll
             for (int j = 0; j < ROWS; ++j)
@@ -424,7 +434,7 @@ namespace
         {
 #pragma unroll
             for (int j = 0; j < ROWS; ++j)
-                dest0[j] = slot[min(NTH * j + lane, nloc - 1)];
+                dest0[j] = (j < own_rows ? dofs : slot)[min(NTH * j + lane, nloc - 1)];
         }
 
         // accumulate: elements of one colour touch disjoint dofs
@@ -1466,9 +1476,12 @@ namespace
 
         if constexpr (!EARLY)
         {
+            // rows of 64 local dofs that hold owned dofs only (the plan numbers those first): the destination is the gather
+            // index, re-read from the lines the gather brought on chip instead of the destination list
+            const int own_rows = ONE ? (A.own_count[first] >> 6) : 0;
 #pragma unroll
             for (int j = 0; j < ROWS; ++j)
-                dest0[j] = slot[min(64 * j + lane, ntot - 1)];
+                dest0[j] = (j < own_rows ? dofs : slot)[min(64 * j + lane, ntot - 1)];
         }
 
         // accumulate in colour phases (both patches at once: they use different halves of ys)
@@ -2575,14 +2588,17 @@ extern "C"
         size_t exclusive = 0;
         for (int s : slot_of)
             exclusive += s >= 0;
-        // destination list of the write-out: one entry per local dof (slot_of); the lane form reads only the rows of 64 that hold
-        // border dofs
+        // destination list of the write-out (slot_of): the plan kernels read it only for the rows of local dofs that hold border
+        // dofs -- rows of 64 (helm_lane_kernel, op_patch_kernel with one patch per wavefront) or of 2 pe (helm_patch_kernel);
+        // the matrix-core kernels and op_patch_kernel with two patches per wavefront read all of it
         size_t dest_entries = dof_list.size();
-        if (p->pair_layout)
+        const bool fused_plan = nqS > 0 && nqM > 0;
+        const int dest_row = mfma ? 0 : (fused_plan ? (p->pair_layout ? 64 : 2 * pe) : (pe == 64 ? 64 : 0));
+        if (dest_row > 0)
         {
             dest_entries = n_patches; // own_count
             for (int q = 0; q < n_patches; ++q)
-                dest_entries += (dof_off[q + 1] - dof_off[q]) - (own_count[q] / 64) * 64;
+                dest_entries += (dof_off[q + 1] - dof_off[q]) - (own_count[q] / dest_row) * dest_row;
         }
         const size_t dest_bytes = dest_entries * 4;
         p->bytes_actual = (size_t)nG * 8 + (size_t)nA * 8 + lidx.size() * 4 + colour.size() + dof_list.size() * (4 + 16) + dest_bytes + // dof (gather), x
