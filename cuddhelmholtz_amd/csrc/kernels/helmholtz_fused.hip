@@ -45,6 +45,7 @@ struct cuddh_helmholtz_plan
     int *dof_off = nullptr;   // [n_patches + 1] offsets into dof_list / slot_of
     int *dof_list = nullptr;  // global dof of every patch-local dof
     int *slot_of = nullptr;   // where a patch-local dof's result goes: its global dof (>= 0) if the patch owns it, else -(slot in `part`) - 1
+    int dof_stride = 0;       // != 0: dof_list / slot_of are stored with this fixed stride per patch (= max_loc), padded with the last entry
     int *own_count = nullptr; // [n_patches] local dofs [0, own_count) are owned (slot_of == dof_list there), the border dofs come last
     int *patch_nel = nullptr; // elements in the patch (32 except possibly the last)
     uint32_t *lidx = nullptr; // [n_patches][ceil(nb*nb/2)][32]: element nodes 2j, 2j+1 -> patch-local dofs, packed lo | hi << 16
@@ -122,6 +123,7 @@ namespace
     struct HelmArgs
     {
         int ndof, max_loc, ncol, nfcol, nqF, n_slots, n_patches, xcd_chunk;
+        int dof_stride; // != 0: patch p's dof_list / slot_of segment starts at p * dof_stride (no offset load), padded to dof_stride entries
         double omega;
         const int *dof_off, *dof_list, *slot_of, *patch_nel, *face_off, *face_id;
         const int *own_count;
@@ -169,8 +171,10 @@ namespace
         double *ys = lds + 2 * ML; // [2][ML]
         double *yw = (TWO && (lane >> 6) == 0) ? xs : ys; // this wavefront's accumulator
 
-        const int off = A.dof_off[patch];
-        const int nloc = A.dof_off[patch + 1] - off;
+        // (fixed-stride lists: the first index requests do not wait for an offset load; `cap` = highest valid list index)
+        const int nloc = A.dof_off[patch + 1] - A.dof_off[patch];
+        const int off = A.dof_stride ? patch * A.dof_stride : A.dof_off[patch];
+        const int cap = A.dof_stride ? A.dof_stride - 1 : nloc - 1;
         const int *dofs = A.dof_list + off;
 
         const double *Gp = A.Gp + (size_t)patch * 3 * NQS * NQS * PEK + le;
@@ -221,14 +225,14 @@ namespace
 #pragma unroll
             for (int j = 0; j < ROWS; ++j)
                 if (j >= own_rows)
-                    dest0[j] = slot[min(NTH * j + lane, nloc - 1)];
+                    dest0[j] = slot[min(NTH * j + lane, cap)];
         }
-        for (int base = 0; base < nloc; base += NTH * ROWS)
+        for (int base = 0; base == 0 || base < nloc; base += NTH * ROWS) // (the first pass does not wait for nloc)
         {
             int gi[ROWS];
 #pragma unroll
             for (int j = 0; j < ROWS; ++j)
-                gi[j] = dofs[min(base + NTH * j + lane, nloc - 1)];
+                gi[j] = dofs[min(base + NTH * j + lane, cap)];
             if constexpr (EARLY)
                 if (base == 0)
 #pragma unroll
@@ -610,8 +614,10 @@ namespace
         };
         stamp(0);
 
-        const int off = A.dof_off[patch];
-        const int nloc = A.dof_off[patch + 1] - off;
+        // (fixed-stride lists: the first index requests do not wait for an offset load; `cap` = highest valid list index)
+        const int nloc = A.dof_off[patch + 1] - A.dof_off[patch];
+        const int off = A.dof_stride ? patch * A.dof_stride : A.dof_off[patch];
+        const int cap = A.dof_stride ? A.dof_stride - 1 : nloc - 1;
         const int *dofs = A.dof_list + off;
         const double *Gp = A.Gp + (size_t)patch * 3 * NQS * NQS * PEK; // pair layout, see load_pairs
         const double *ap = A.aMp + (size_t)patch * NQM * NQM * PEK;
@@ -674,14 +680,14 @@ namespace
 #pragma unroll
             for (int j = 0; j < ROWS; ++j)
                 if (j >= j_own)
-                    dest0[j] = slot[min(64 * j + lane, nloc - 1)];
+                    dest0[j] = slot[min(64 * j + lane, cap)];
         auto gather_pass = [&](int base, auto first)
         {
             constexpr bool WITH_METRIC = PRE && decltype(first)::value;
             int gi[ROWS];
 #pragma unroll
             for (int j = 0; j < ROWS; ++j)
-                gi[j] = dofs[min(base + 64 * j + lane, nloc - 1)];
+                gi[j] = dofs[min(base + 64 * j + lane, cap)];
             if constexpr (EARLY_DEST && decltype(first)::value)
 #pragma unroll
                 for (int j = 0; j < ROWS; ++j)
@@ -1270,6 +1276,7 @@ namespace
         A.dof_list = p->dof_list;
         A.slot_of = p->slot_of;
         A.own_count = p->own_count;
+        A.dof_stride = p->dof_stride;
         A.patch_nel = p->patch_nel;
         A.face_off = p->face_off;
         A.face_id = p->face_id;
@@ -1314,9 +1321,11 @@ namespace
         const int n_here = ONE ? 1 : min(2, A.n_patches - first);
 
         // the dof lists of the two patches are adjacent: one combined list, split at n0
-        const int off = A.dof_off[first];
-        const int n0 = A.dof_off[first + 1] - off;
-        const int ntot = A.dof_off[first + n_here] - off;
+        // (one patch per wavefront: fixed-stride lists, the first index requests do not wait for an offset load)
+        const int n0 = A.dof_off[first + 1] - A.dof_off[first];
+        const int ntot = A.dof_off[first + n_here] - A.dof_off[first];
+        const int off = (ONE && A.dof_stride) ? first * A.dof_stride : A.dof_off[first];
+        const int cap = (ONE && A.dof_stride) ? A.dof_stride - 1 : ntot - 1;
         const int *dofs = A.dof_list + off;
 
         // requests that do not depend on the LDS copy of x go out first (see helm_patch_kernel)
@@ -1350,12 +1359,12 @@ namespace
             for (int j = 0; j < ROWS; ++j)
                 dest0[j] = slot[min(64 * j + lane, ntot - 1)];
         }
-        for (int base = 0; base < ntot; base += 64 * ROWS)
+        for (int base = 0; base == 0 || base < ntot; base += 64 * ROWS) // (the first pass does not wait for ntot)
         {
             int gi[ROWS];
 #pragma unroll
             for (int j = 0; j < ROWS; ++j)
-                gi[j] = dofs[min(base + 64 * j + lane, ntot - 1)];
+                gi[j] = dofs[min(base + 64 * j + lane, cap)];
             double xv[ROWS];
 #pragma unroll
             for (int j = 0; j < ROWS; ++j)
@@ -2487,8 +2496,32 @@ extern "C"
                 err = e;
         };
         ok(upload(&p->dof_off, dof_off));
-        ok(upload(&p->dof_list, dof_list));
-        ok(upload(&p->slot_of, slot_of));
+        // Fixed stride for the per-patch lists (helm_lane_kernel, helm_patch_kernel, op_patch_kernel with one patch per wavefront):
+        // segment p starts at p * max_loc and is padded with its last entry, so a kernel can request its first indices without
+        // waiting for dof_off -- one dependent (scalar) round trip less at the head of every wavefront's chain.  The matrix-core
+        // kernels and op_patch_kernel with two patches per wavefront keep the packed lists.
+        const bool fixed_stride = !mfma && (pe == 64 || (nqS > 0 && nqM > 0));
+        if (fixed_stride)
+        {
+            std::vector<int> dl((size_t)n_patches * max_loc), so((size_t)n_patches * max_loc);
+            for (int q = 0; q < n_patches; ++q)
+            {
+                const int n = dof_off[q + 1] - dof_off[q];
+                for (int i = 0; i < max_loc; ++i)
+                {
+                    dl[(size_t)q * max_loc + i] = dof_list[dof_off[q] + std::min(i, n - 1)];
+                    so[(size_t)q * max_loc + i] = slot_of[dof_off[q] + std::min(i, n - 1)];
+                }
+            }
+            p->dof_stride = max_loc;
+            ok(upload(&p->dof_list, dl));
+            ok(upload(&p->slot_of, so));
+        }
+        else
+        {
+            ok(upload(&p->dof_list, dof_list));
+            ok(upload(&p->slot_of, slot_of));
+        }
         ok(upload(&p->own_count, own_count));
         ok(upload(&p->patch_nel, patch_nel));
         ok(upload(&p->lidx, lidx));
