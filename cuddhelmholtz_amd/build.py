@@ -106,9 +106,28 @@ def build_examples(verbose: bool = False) -> list[Path]:
     jobs = [(CSRC / "examples" / "ddh_solve.cpp", "ddh_solve"), (CSRC / "examples" / "helmholtz_solve.cpp", "helmholtz_solve")]
     if REFERENCE_EXAMPLES.exists():
         jobs += [(REFERENCE_EXAMPLES / f"{n}.cpp", f"{n}_reference_driver") for n in ("DDH", "Poisson", "Helmholtz")]
+    # the reference's OWN test suite (tests/test.cpp + quadrature_rule, basis, gmres, linalg, mass, stiffness and the text-mesh
+    # loader), every file compiled where it lies and unchanged, against csrc/include/cuddh.hpp; the mesh fixture it reads is
+    # the copy under tests/golden/ (data)
+    REFERENCE_TESTS = REFERENCE_EXAMPLES.parent / "tests"
+    if REFERENCE_TESTS.exists():
+        jobs.append((sorted(REFERENCE_TESTS.glob("*.cpp")), "reference_tests_driver"))
     outs = []
     for src, name in jobs:
         out = EXAMPLES_DIR / name
+        if isinstance(src, list):
+            if out.exists() and out.stat().st_mtime > max(max(f.stat().st_mtime for f in src), LIB_PATH.stat().st_mtime):
+                outs.append(out)
+                continue
+            cmd = [hipcc(), "-O2", "-std=c++17", "-x", "hip", f"--offload-arch={ARCH}", "-munsafe-fp-atomics",
+                   *[f"-I{p}" for p in INCLUDES], f"-I{src[0].parent}",
+                   '-DUNSTRUCTURED_SQUARE_MESH_DIR="/root/repo/tests/golden/unstructured_square"', *map(str, src), "-o", str(out),
+                   f"-L{LIB_DIR}", "-lcuddh_amd", "-Wl,-rpath,$ORIGIN/../../cuddhelmholtz_amd/lib"]
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError(f"building {name} failed:\n{r.stderr}")
+            outs.append(out)
+            continue
         if out.exists() and out.stat().st_mtime > max(src.stat().st_mtime, LIB_PATH.stat().st_mtime):
             outs.append(out)
             continue
