@@ -112,6 +112,8 @@ def main() -> None:
     ap.add_argument("--sharded-apply", action="store_true",
                     help="N > 1: also time the partitioned global Helmholtz apply (element partition + halo exchanges, "
                          "cuddhelmholtz_amd.dist.ShardedHelmholtz) and report its aggregate rate as `roofline_sharded`")
+    ap.add_argument("--rank-grid", default="", metavar="GXxGY",
+                    help="N > 1: ranks own rectangles of the subdomain grid (GX x GY = N, SURVEY 8e) instead of strips of block rows")
     ap.add_argument("--overlap", action="store_true",
                     help="N > 1: split schedule (boundary subdomains first, on a second stream with issue priority, exchange behind "
                          "them, interior meanwhile); default is exchange-after-solve")
@@ -199,8 +201,17 @@ def main() -> None:
     if world > 1 and args.exchange == "neighbour":
         ok, sh_nb, b_nb = 0.0, None, None
         try:
+            dom_rank = None
+            if args.rank_grid:
+                from cuddhelmholtz_amd.dist import rank_grid_map
+
+                gx, gy = (int(v) for v in args.rank_grid.lower().split("x"))
+                if gx * gy != world:
+                    raise SystemExit(f"bench.py: --rank-grid {args.rank_grid} does not have {world} ranks")
+                ndx = nx // info["nel1d"]
+                dom_rank = rank_grid_map(ndx, nd // ndx, gx, gy)
             sh_nb = NeighbourShardedDDH(F, nd, rank, world, device=dev, host_staging=staged, overlap=args.overlap,
-                                        set_stream=cd.use_torch_stream)
+                                        set_stream=cd.use_torch_stream, dom_rank=dom_rank)
             b_nb = torch.zeros_like(b)
             sh_nb.rhs(f, b_nb)
             # traces are copied, not summed: the assembled vector must be bitwise the all-reduce result
@@ -333,6 +344,7 @@ def main() -> None:
                                       f"send/recv of {sum(i.numel() for i in getattr(sh, 'send_idx', {}).values()) * 4 / 1024:.0f} KiB to "
                                       f"{len(getattr(sh, 'send_idx', {}))} neighbour rank(s) per step (rank 0), all-reduce of each inner product"}[exchange]
                         + (", split schedule (boundary subdomains first with issue priority, exchange behind them)" if (args.overlap and exchange == "neighbour") else "")
+                        + (f", rank grid {args.rank_grid} (rectangles of the subdomain grid)" if (args.rank_grid and exchange == "neighbour") else "")
                         + (f" [{exchange_note}]" if exchange_note else ""),
             "setup_seconds": round(t_constructors, 3),  # Mesh2D + H1Space + load vector / coefficient + DDH constructor + plan
             "rhs_and_exchange_check_seconds": round(t_setup - t_constructors, 3),  # DDH::rhs (one pass of local solves) [+ N > 1 start-up check]

@@ -134,6 +134,19 @@ def _runs(ids):
     return [tuple(r) for r in out]
 
 
+def rank_grid_map(ndx: int, ndy: int, gx: int, gy: int):
+    """Subdomain -> rank for a gx x gy grid of ranks over the ndx x ndy block grid of a structured DDH (subdomain
+    bx + ndx * by, reference source/DDH.cpp:341-344): contiguous, balanced rectangles, rank = rx + gx * ry -- at most four face
+    neighbours per rank.  gx = 1 gives the strips of block rows `partition` describes."""
+    import numpy as np
+
+    if gx < 1 or gy < 1 or gx > ndx or gy > ndy:
+        raise ValueError("rank grid does not fit the block grid")
+    rx = (np.arange(ndx) * gx) // ndx
+    ry = (np.arange(ndy) * gy) // ndy
+    return (rx[None, :] + gx * ry[:, None]).reshape(-1).astype(np.int64)
+
+
 class TraceExchange:
     """Who owns, sends and receives which trace slots, from the slot table B(mx_fdof, 2, n_domains) of the DDH
     constructor (reference source/DDH.cpp:425-440): B(i,0,S) is the slot subdomain S reads for its face dof i,
@@ -142,12 +155,17 @@ class TraceExchange:
     owner(slot) = rank of the subdomain that reads it (else of the one that writes it; slots nobody touches --
     the reference's orphan slots at cross points -- stay zero everywhere)."""
 
-    def __init__(self, B, n_domains: int, mx_fdof: int, n_lambda: int, rank: int, world: int):
+    def __init__(self, B, n_domains: int, mx_fdof: int, n_lambda: int, rank: int, world: int, dom_rank=None):
         import numpy as np
 
         B = np.asarray(B, dtype=np.int64).reshape(n_domains, 2, mx_fdof)
-        upper = np.asarray([partition(n_domains, r, world)[1] for r in range(world)])
-        dom_rank = np.searchsorted(upper, np.arange(n_domains), side="right")
+        if dom_rank is None:  # contiguous ranges (strips of block rows on a structured block grid)
+            upper = np.asarray([partition(n_domains, r, world)[1] for r in range(world)])
+            dom_rank = np.searchsorted(upper, np.arange(n_domains), side="right")
+        else:  # any assignment, e.g. rank_grid_map
+            dom_rank = np.asarray(dom_rank, dtype=np.int64)
+            if dom_rank.shape != (n_domains,) or dom_rank.min() < 0 or dom_rank.max() >= world:
+                raise ValueError("dom_rank: one rank in [0, world) per subdomain")
         dom_of = np.repeat(np.arange(n_domains), mx_fdof)
 
         def slot_to_domain(col):
@@ -165,7 +183,12 @@ class TraceExchange:
         wrank = np.where(writer >= 0, dom_rank[np.maximum(writer, 0)], -1)
 
         self.rank, self.world, self.n_lambda = rank, world, n_lambda
-        self.d0, self.d1 = partition(n_domains, rank, world)
+        self.domains = np.flatnonzero(dom_rank == rank)  # this rank's subdomains, increasing
+        contiguous = self.domains.size > 0 and int(self.domains[-1] - self.domains[0]) + 1 == self.domains.size
+        # [d0, d1) when the rank's subdomains are one range (always so without dom_rank), else None: use `domains`
+        self.d0, self.d1 = (int(self.domains[0]), int(self.domains[-1]) + 1) if contiguous else (None, None)
+        if self.domains.size == 0:
+            self.d0 = self.d1 = 0
         self.owned_slots = np.flatnonzero(owner == rank)
         self.send_slots, self.recv_slots = {}, {}
         for s in range(world):
@@ -180,9 +203,7 @@ class TraceExchange:
         sent = np.concatenate(list(self.send_slots.values())) if self.send_slots else np.zeros(0, dtype=np.int64)
         boundary = np.unique(writer[sent])
         self.boundary_ranges = _runs(boundary)
-        mask = np.ones(self.d1 - self.d0, dtype=bool)
-        mask[boundary - self.d0] = False
-        self.interior_ranges = _runs(np.flatnonzero(mask) + self.d0)
+        self.interior_ranges = _runs(np.setdiff1d(self.domains, boundary, assume_unique=True))
 
     def entries(self, slots):
         """vector entries (lambda and mu halves) of a set of slots"""
@@ -202,21 +223,33 @@ class NeighbourShardedDDH:
     and run the interior subdomains meanwhile (`set_stream` must point the engine at torch's current stream)."""
 
     def __init__(self, engine, n_domains: int, rank: int = 0, world: int = 1, group=None, device=None, host_staging: bool = False,
-                 overlap: bool = False, set_stream=None, dry_run: bool = False):
+                 overlap: bool = False, set_stream=None, dry_run: bool = False, dom_rank=None):
         import torch
 
         self.engine, self.rank, self.world, self.group = engine, rank, world, group
         self.host_staging, self.overlap, self.set_stream, self.dry_run = host_staging, overlap, set_stream, dry_run
         info = engine.info()
-        self.ex = TraceExchange(engine.table("B"), n_domains, info["mx_fdof"], info["n_lambda"], rank, world)
+        # dom_rank: subdomain -> rank (e.g. rank_grid_map for a gx x gy grid of ranks); default: contiguous ranges
+        self.ex = TraceExchange(engine.table("B"), n_domains, info["mx_fdof"], info["n_lambda"], rank, world, dom_rank)
         self.d0, self.d1 = self.ex.d0, self.ex.d1
+        self._lists = {}  # device lists of subdomain ids for the one-launch entry point
+        # The split schedule launches boundary and interior subdomains separately.  A workgroup of the wavefront kernels
+        # holds 4 wavefronts (8 subdomains for n_basis 8), so a boundary count that is not a multiple of that leaves both
+        # launches with a partial workgroup -- one workgroup more than the unsplit launch, which at 8,192 subdomains per rank
+        # (exactly one resident round) means a second round for it (+5 ms of 44).  Up to 7 interior subdomains therefore
+        # join the boundary launch.
+        import numpy as np
+
+        boundary = np.asarray([d for a, b in self.ex.boundary_ranges for d in range(a, b)], dtype=np.int64)
+        interior = np.asarray([d for a, b in self.ex.interior_ranges for d in range(a, b)], dtype=np.int64)
+        pad = min((-boundary.size) % 8, interior.size) if boundary.size else 0
+        self._ids = {"all": self.ex.domains, "boundary": np.sort(np.concatenate([boundary, interior[:pad]])), "interior": interior[pad:]}
         self.device = torch.device("cpu") if device is None else torch.device(device)
         as_idx = lambda a: torch.from_numpy(self.ex.entries(a)).to(self.device)  # noqa: E731
         self.send_idx = {s: as_idx(a) for s, a in self.ex.send_slots.items()}
         self.recv_idx = {s: as_idx(a) for s, a in self.ex.recv_slots.items()}
         self.owned_idx = as_idx(self.ex.owned_slots)
         self._side = torch.cuda.Stream(self.device) if (overlap and self.device.type == "cuda") else None
-        self._boundary_list = None  # device list of the subdomains other ranks wait for (split schedule)
 
     # ---- communication
     def reduce(self, t) -> None:
@@ -264,22 +297,38 @@ class NeighbourShardedDDH:
         del sbuf
 
     # ---- the operator
+    def _solve(self, which: str, f, lam, out) -> None:
+        """local solves of "all" / "boundary" / "interior" subdomains of this rank: one range call when they are one range,
+        one listed launch when the engine has that entry point (cuddh_hip_ddh_apply_list_*), else range by range"""
+        import torch
+
+        ranges = _runs(self._ids[which])
+        if not ranges:
+            return
+        listed = getattr(self.engine, "local_traces_listed", None)
+        if len(ranges) == 1 or listed is None:
+            for a, b in ranges:
+                self.engine.local_traces(a, b, f, lam, out)
+            return
+        if which not in self._lists:
+            ids = [s for a, b in ranges for s in range(a, b)]
+            self._lists[which] = torch.tensor(ids, dtype=torch.int32, device=self.device)
+        listed(self._lists[which], f, lam, out)
+
     def traces(self, f, lam, out) -> None:
         """out <- traces written by this rank's subdomains into slots it owns + traces received from its neighbours"""
         out.zero_()
         if self.world == 1:
-            self.engine.local_traces(self.d0, self.d1, f, lam, out)
+            self._solve("all", f, lam, out)
             return
         if not self.overlap:
-            self.engine.local_traces(self.d0, self.d1, f, lam, out)
+            self._solve("all", f, lam, out)
             self._finish_exchange(out, self._start_exchange(out))
             return
         if self._side is None:  # no streams on this device: same order, nothing to overlap
-            for a, b in self.ex.boundary_ranges:
-                self.engine.local_traces(a, b, f, lam, out)
+            self._solve("boundary", f, lam, out)
             pending = self._start_exchange(out)
-            for a, b in self.ex.interior_ranges:
-                self.engine.local_traces(a, b, f, lam, out)
+            self._solve("interior", f, lam, out)
             self._finish_exchange(out, pending)
             return
         import torch
@@ -291,28 +340,18 @@ class NeighbourShardedDDH:
         # ONE launch for all boundary ranges, so that boundary + interior wavefronts together are exactly the residents of the
         # unsplit launch (queued one behind the other, the pieces leave SIMDs with one subdomain more than the rest: 49 ms).
         prio = getattr(self.engine, "set_wave_priority", None)
-        listed = getattr(self.engine, "local_traces_listed", None)
-        if listed and self._boundary_list is None:
-            ids = [s for a, b in self.ex.boundary_ranges for s in range(a, b)]
-            self._boundary_list = torch.tensor(ids, dtype=torch.int32, device=self.device)
         main = torch.cuda.current_stream(self.device)
         self._side.wait_stream(main)
         with torch.cuda.stream(self._side):
             self.set_stream()
             if prio:
                 prio(True)
-            if listed:
-                if self._boundary_list.numel():
-                    listed(self._boundary_list, f, lam, out)
-            else:
-                for a, b in self.ex.boundary_ranges:
-                    self.engine.local_traces(a, b, f, lam, out)
+            self._solve("boundary", f, lam, out)
             if prio:
                 prio(False)
             pending = self._start_exchange(out)
         self.set_stream()
-        for a, b in self.ex.interior_ranges:
-            self.engine.local_traces(a, b, f, lam, out)
+        self._solve("interior", f, lam, out)
         main.wait_stream(self._side)
         self._finish_exchange(out, pending)
 
@@ -328,7 +367,8 @@ class NeighbourShardedDDH:
     def postprocess(self, lam, f, u) -> None:
         """reference DDH::postprocess (source/DDH.cpp:669-695); u is summed over the ranks (once per solve)"""
         u.zero_()
-        self.engine.local_solution(self.d0, self.d1, lam, f, u, False)
+        for a, b in _runs(self.ex.domains):  # (once per solve: range by range when the rank's subdomains are a rectangle)
+            self.engine.local_solution(a, b, lam, f, u, False)
         self.reduce(u)
 
     def full(self, v):

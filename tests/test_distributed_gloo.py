@@ -12,7 +12,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 import oracle
-from cuddhelmholtz_amd.dist import NeighbourShardedDDH, ShardedDDH, TraceExchange, partition
+from cuddhelmholtz_amd.dist import NeighbourShardedDDH, ShardedDDH, TraceExchange, partition, rank_grid_map
 
 
 class OracleEngine:
@@ -148,13 +148,14 @@ def solve_partitioned(sh, O, f, ndof):
     return sh.full(b), sh.full(lam), u, info["num_matvec"]
 
 
-def worker_neighbour(rank, world, port, out_dir, overlap):
+def worker_neighbour(rank, world, port, out_dir, overlap, grid=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         O, f, ndof = build_case16()
-        sh = NeighbourShardedDDH(OracleEngine(O), O.t.n_domains, rank, world, overlap=overlap)
+        dom_rank = rank_grid_map(4, 4, *grid) if grid else None  # 16^2 elements, n_basis 4: 4 x 4 blocks
+        sh = NeighbourShardedDDH(OracleEngine(O), O.t.n_domains, rank, world, overlap=overlap, dom_rank=dom_rank)
         b, lam, u, nmv = solve_partitioned(sh, O, f, ndof)
         torch.save({"b": b, "lam": lam, "u": u, "nmv": nmv}, os.path.join(out_dir, f"rank{rank}.pt"))
     finally:
@@ -181,18 +182,40 @@ def test_trace_exchange_tables():
                     b = ex[s].recv_slots.get(r, np.zeros(0, dtype=np.int64))
                     assert np.array_equal(a, b)
             doms = sorted(d for a, b in ex[r].boundary_ranges + ex[r].interior_ranges for d in range(a, b))
-            assert doms == list(range(ex[r].d0, ex[r].d1))
+            assert doms == list(range(ex[r].d0, ex[r].d1)) == list(ex[r].domains)
             if world > 1:
                 assert ex[r].boundary_ranges, "every rank of a connected block grid feeds a neighbour"
         if world == 2:  # 4x4 blocks split into two strips of two block rows: one block row feeds the other rank
             assert ex[0].boundary_ranges == [(4, 8)] and ex[1].boundary_ranges == [(8, 12)]
+    # rank grids: rectangles of the block grid, at most four face neighbours, nothing between diagonal ranks
+    for gx, gy in ((2, 2), (4, 1), (1, 4), (2, 1), (4, 2)):
+        world = gx * gy
+        dr = rank_grid_map(4, 4, gx, gy)
+        assert np.array_equal(np.bincount(dr, minlength=world), np.full(world, 16 // world))
+        ex = [TraceExchange(B, t.n_domains, t.mx_fdof, t.n_lambda, r, world, dr) for r in range(world)]
+        owned = np.concatenate([e.owned_slots for e in ex])
+        assert np.array_equal(np.sort(owned), touched)
+        for r in range(world):
+            rx, ry = r % gx, r // gx
+            for s in range(world):
+                if r != s:
+                    a = ex[r].send_slots.get(s, np.zeros(0, dtype=np.int64))
+                    assert np.array_equal(a, ex[s].recv_slots.get(r, np.zeros(0, dtype=np.int64)))
+                    face_neighbour = abs(s % gx - rx) + abs(s // gx - ry) == 1
+                    assert bool(a.size) == face_neighbour, (gx, gy, r, s)
+            doms = sorted(d for a, b in ex[r].boundary_ranges + ex[r].interior_ranges for d in range(a, b))
+            assert doms == list(ex[r].domains) == list(np.flatnonzero(dr == r))
+            assert (ex[r].d0 is None) == (gx > 1 and 16 // world > 4 // gx)  # one range only when a rank's rectangle is one block row
+    assert np.array_equal(rank_grid_map(4, 4, 1, 2), [0] * 8 + [1] * 8)  # gx = 1: the strips `partition` gives
 
 
-@pytest.mark.parametrize("world,overlap", [(2, False), (3, True)])
-def test_neighbour_exchange_reproduces_one_rank(tmp_path, world, overlap):
+@pytest.mark.parametrize("world,overlap,grid", [(2, False, None), (3, True, None), (4, True, (2, 2)), (2, False, (2, 1))])
+def test_neighbour_exchange_reproduces_one_rank(tmp_path, world, overlap, grid):
+    """grid: SURVEY 8e's gx x gy rectangles of the block grid instead of strips of block rows (a rank's subdomains are then
+    not one range; cross points sit between four ranks)."""
     O, f, ndof = build_case16()
     single = solve(ShardedDDH(OracleEngine(O), O.t.n_domains), O, f, ndof)
-    mp.spawn(worker_neighbour, args=(world, free_port(), str(tmp_path), overlap), nprocs=world, join=True)
+    mp.spawn(worker_neighbour, args=(world, free_port(), str(tmp_path), overlap, grid), nprocs=world, join=True)
     for r in range(world):
         got = torch.load(os.path.join(tmp_path, f"rank{r}.pt"), weights_only=True)
         assert torch.equal(got["b"], single[0])  # traces are copied, never summed: bitwise

@@ -20,8 +20,10 @@ def free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("precision,overlap", [("f64", False), ("f32", True)])
-def test_two_processes_neighbour_exchange(cuda, tmp_path, precision, overlap):
+@pytest.mark.parametrize("precision,overlap,grid", [("f64", False, None), ("f32", True, None), ("f32", False, "2x1"), ("f32", True, "2x1")])
+def test_two_processes_neighbour_exchange(cuda, tmp_path, precision, overlap, grid):
+    """grid "2x1": the ranks take the left and the right half of the block grid (SURVEY 8e's gx x gy rectangles), so a rank's
+    subdomains are half of every block row -- not one range: the local solves go through the listed one-launch entry point."""
     import torch
 
     sys.path.insert(0, str(ROOT / "tests"))
@@ -32,7 +34,7 @@ def test_two_processes_neighbour_exchange(cuda, tmp_path, precision, overlap):
     nx, nb, world = 32, 4, 2
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), WORLD_SIZE=str(world))
     procs = [subprocess.Popen([sys.executable, str(ROOT / "tests" / "sharded_worker.py"), str(nx), str(nb), precision,
-                               "1" if overlap else "0", str(tmp_path)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                               "1" if overlap else "0", str(tmp_path)] + ([grid] if grid else []), env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
                               stderr=subprocess.STDOUT, text=True) for r in range(world)]
     logs = [p.communicate(timeout=600)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(logs)
@@ -56,10 +58,12 @@ def test_two_processes_neighbour_exchange(cuda, tmp_path, precision, overlap):
         assert rel(got["u"], u.cpu()) < (1e-9 if precision == "f64" else 2e-3)
         boundary, interior = got["ranges"]
         assert boundary and interior
+        if grid:  # 8 x 8 blocks, left / right halves: one boundary column and three interior columns per block row
+            assert len(boundary) == 8 and len(interior) == 8
 
 
-@pytest.mark.parametrize("split", [False, True])
-def test_bench_two_rank_rehearsal(cuda, split):
+@pytest.mark.parametrize("split,grid", [(False, ""), (True, ""), (True, "2x1")])
+def test_bench_two_rank_rehearsal(cuda, split, grid):
     """bench.py's N > 1 code path (partition, neighbour exchange chosen after its start-up cross-check against the
     all-reduce assembly, reduced inner products, max-over-ranks timing, one JSON line from rank 0) with two ranks
     sharing the GPU over gloo; with and without the split schedule (boundary subdomains as one listed launch with issue
@@ -69,7 +73,7 @@ def test_bench_two_rank_rehearsal(cuda, split):
 
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(free_port()), str(ROOT / "bench.py"), "--gpus", "2", "--rehearse-gloo", "--nx", "64", "--steps", "3",
-           "--warmup", "1", "--no-roofline"] + (["--overlap"] if split else [])
+           "--warmup", "1", "--no-roofline"] + (["--overlap"] if split else []) + (["--rank-grid", grid] if grid else [])
     r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout + r.stderr
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -78,6 +82,7 @@ def test_bench_two_rank_rehearsal(cuda, split):
     assert out["n_gpus"] == 2 and out["steps"] == 3 and out["scaling"] == "strong" and out["config"]["finite"]
     assert "partitioned by slot ownership" in out["config"]["sharding"] and "fell back" not in out["config"]["sharding"]
     assert ("split schedule" in out["config"]["sharding"]) == split
+    assert ("rank grid" in out["config"]["sharding"]) == bool(grid)
     assert "cpu_baseline" not in out  # N = 1 only
 
 
