@@ -269,3 +269,31 @@ def test_ddh_properties_at_full_size(cuda, big):
         mask[r.owned_idx] = False
         assert not bool(out_r[mask].any())  # zero outside the owned entries
     assert torch.equal(torch.stack(outs).sum(0), upd_whole)
+
+    # the same with a 2 x 4 grid of ranks (SURVEY 8e's rectangles: 128 x 64 subdomains each, a rank's subdomains are 64 runs of
+    # 128): local solves through the listed one-launch entry point, at most 3 face neighbours here, nothing between diagonals
+    from cuddhelmholtz_amd.dist import rank_grid_map
+
+    dom_rank = rank_grid_map(256, 256, 2, 4)
+    grid = [NeighbourShardedDDH(F, 65536, r, world, device=cuda, dry_run=True, dom_rank=dom_rank) for r in range(world)]
+    outs = []
+    for r in grid:
+        assert r.ex.d0 is None and r.ex.domains.size == 8192
+        lam_r = torch.zeros_like(lam)
+        lam_r[r.owned_idx] = lam[r.owned_idx]
+        out_r = torch.zeros_like(lam)
+        r._solve("all", None, lam_r, out_r)
+        outs.append(out_r)
+        rx, ry = r.rank % 2, r.rank // 2
+        assert sorted(r.send_idx) == sorted(s for s in range(world) if abs(s % 2 - rx) + abs(s // 2 - ry) == 1)
+        assert sum(i.numel() for i in r.send_idx.values()) < 2 * 2 * (256 * 13)  # less than a strip sends
+    for r in grid:
+        for s_rank, idx in r.send_idx.items():
+            assert torch.equal(grid[s_rank].recv_idx[r.rank], idx)
+            outs[s_rank][idx] = outs[r.rank][idx]
+    for r in grid:
+        for idx in r.send_idx.values():
+            outs[r.rank][idx] = 0
+    assert torch.equal(torch.stack(outs).sum(0), upd_whole)
+    owned = torch.cat([r.owned_idx for r in grid])
+    assert owned.numel() == torch.unique(owned).numel()
