@@ -2,7 +2,10 @@
 16,384 subdomains, fp32 local solves on kernel 5): rhs -> gmres(I - T) -> postprocess as in examples/DDH.cpp:141-144, with the
 coefficient a = 1 (with the example's disk the reference's own time step is unstable where a = 0.2: DESIGN 5.2) and a long
 restart.  Prints the residual after every cycle (verbose = 2), then the true relative residual of the trace system and the
-norm of the postprocessed solution.  usage: ddh_converged_solve.py [nx=512] [m=400] [tol=1e-4] [max_seconds=950]"""
+norm of the postprocessed solution.
+usage: ddh_converged_solve.py [nx=512] [m=400] [tol=1e-4] [max_seconds=950] [rule=baseline|example] [coef=one|disk]
+rule "example": omega = 2 pi nx / 10 (examples/DDH.cpp:109: five elements per wavelength, where the reference's time step is
+stable also with its disk coefficient) instead of BASELINE's omega = pi nx / 32."""
 import math
 import sys
 import time
@@ -18,19 +21,25 @@ nx = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 m = int(sys.argv[2]) if len(sys.argv) > 2 else 400
 tol = float(sys.argv[3]) if len(sys.argv) > 3 else 1e-4
 max_seconds = float(sys.argv[4]) if len(sys.argv) > 4 else 950.0
-omega = math.pi * nx / 32.0
+rule = sys.argv[5] if len(sys.argv) > 5 else "baseline"
+coef = sys.argv[6] if len(sys.argv) > 6 else "one"
+omega = math.pi * nx / 32.0 if rule == "baseline" else 2.0 * math.pi * nx / 10.0
 dev = torch.device("cuda:0")
 cd.use_torch_stream()
 fem = cd.H1Space(cd.Mesh2D.uniform_rect(nx, -1.0, 1.0, nx, -1.0, 1.0), cd.Basis(4))
 ndof = fem.size()
 f = torch.zeros(2 * ndof, dtype=torch.float64, device=dev)
 cd.linear_functional(fem, cd.GAUSSIANS, f[:ndof], param=omega)
-F = cd.DDH(omega, np.ones(ndof), fem, nx, nx, precision="f32")
+a = torch.ones(ndof, dtype=torch.float64, device=dev)
+if coef == "disk":  # examples/DDH.cpp:122-125
+    cd.linear_functional(fem, cd.ALPHA_DISK, a)
+    cd.DiagInvMassMatrix(fem).action(a, a)
+F = cd.DDH(omega, a.cpu().numpy(), fem, nx, nx, precision="f32")
 n = F.size()
 b = torch.zeros(n, dtype=torch.float32, device=dev)
 lam = torch.zeros_like(b)
 F.rhs(f, b)
-print(f"DDH solve {nx}x{nx}, omega = {omega / math.pi:g} pi, a = 1, kernel {F.info()['kernel']}, {n} traces, GMRES({m}), tol {tol:g}", flush=True)
+print(f"DDH solve {nx}x{nx}, omega = {omega / math.pi:g} pi ({rule} rule), coefficient {coef}, kernel {F.info()['kernel']}, {n} traces, GMRES({m}), tol {tol:g}", flush=True)
 t0 = time.perf_counter()
 out = cd.gmres(n, lam, F, b, m, 1000, tol, verbose=2, max_seconds=max_seconds)
 torch.cuda.synchronize()
