@@ -3,7 +3,8 @@
 coefficient a = 1 (with the example's disk the reference's own time step is unstable where a = 0.2: DESIGN 5.2) and a long
 restart.  Prints the residual after every cycle (verbose = 2), then the true relative residual of the trace system and the
 norm of the postprocessed solution.
-usage: ddh_converged_solve.py [nx=512] [m=400] [tol=1e-4] [max_seconds=950] [rule=baseline|example] [coef=one|disk]
+usage: ddh_converged_solve.py [nx=512] [m=400] [tol=1e-4] [max_seconds=950] [rule=baseline|example] [coef=one|disk] [also_f64=0|1]
+also_f64 = 1: the same solve with fp64 local solves (DDH64, tolerance tol / 100) and the distance between the two solutions.
 rule "example": omega = 2 pi nx / 10 (examples/DDH.cpp:109: five elements per wavelength, where the reference's time step is
 stable also with its disk coefficient) instead of BASELINE's omega = pi nx / 32."""
 import math
@@ -52,3 +53,19 @@ F.postprocess(lam, f, u)
 print(f"success = {out.success}, {out.num_iter} cycles, {out.num_matvec} matvecs, {t:.1f} s ({2.0 * ndof * out.num_matvec / t / 1e6:.1f} M DoF*iter/s)")
 print(f"true relative residual ||b - (I - T) lambda|| / ||b|| = {true_res:.3e}; ||u||_2 = {float(torch.linalg.norm(u)):.6e}, finite = {bool(torch.isfinite(u).all())}")
 print("relative residual after cycle k: " + " ".join(f"{v / out.res_norm[0]:.2e}" for v in out.res_norm))
+
+if len(sys.argv) > 7 and sys.argv[7] == "1":
+    F64 = cd.DDH(omega, a.cpu().numpy(), fem, nx, nx, precision="f64")
+    b64 = torch.zeros(n, dtype=torch.float64, device=dev)
+    lam64 = torch.zeros_like(b64)
+    F64.rhs(f, b64)
+    t0 = time.perf_counter()
+    out64 = cd.gmres(n, lam64, F64, b64, m, 1000, tol / 100.0, verbose=0, max_seconds=max_seconds)
+    torch.cuda.synchronize()
+    t64 = time.perf_counter() - t0
+    u64 = torch.zeros_like(u)
+    F64.postprocess(lam64, f, u64)
+    print(f"fp64 local solves (kernel {F64.info()['kernel']}): success = {out64.success}, {out64.num_matvec} matvecs, {t64:.1f} s, "
+          f"relative residual {out64.res_norm[-1] / out64.res_norm[0]:.3e}")
+    print(f"fp32 solve (tol {tol:g}) vs fp64 solve (tol {tol / 100:g}): ||u32 - u64|| / ||u64|| = {float(torch.linalg.norm(u - u64) / torch.linalg.norm(u64)):.3e}; "
+          f"traces: {float(torch.linalg.norm(lam.double() - lam64) / torch.linalg.norm(lam64)):.3e}")
