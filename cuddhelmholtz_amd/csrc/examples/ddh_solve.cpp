@@ -3,7 +3,8 @@
 //   ddh_solve [nx=128] [n_basis=4] [omega_over_pi=25.6] [gmres_m=20] [maxit=100] [tol=1e-4] [out_dir=solution] [devices=0] [force_rccl=0]
 // Writes <out_dir>/xy.0000 and <out_dir>/ddh.0000 (raw fp64, like the reference) and prints one summary line.
 // devices >= 1: the same solve through cuddh::ddh_solve_multi_gpu (multigpu.hpp): subdomains sharded over that many GPUs of
-// this process, RCCL neighbour exchange; devices = 1 with force_rccl = 1 runs the communicator path on a one-GPU box.
+// this process, RCCL neighbour exchange; devices = 1 with force_rccl = 1 runs the communicator path on a one-GPU box;
+// force_rccl = 2 is the loopback test transport (the ranks share device 0, no RCCL).
 #include <chrono>
 #include <cstdlib>
 #include <string>
@@ -25,7 +26,7 @@ int main(int argc, char **argv)
     const float tol = argc > 6 ? static_cast<float>(std::atof(argv[6])) : 1e-4f;
     const std::string out_dir = argc > 7 ? argv[7] : "solution";
     const int devices = argc > 8 ? std::atoi(argv[8]) : 0;
-    const bool force_rccl = argc > 9 && std::atoi(argv[9]) != 0;
+    const int force_rccl = argc > 9 ? std::atoi(argv[9]) : 0; // transport: 0 auto, 1 RCCL also for one rank, 2 loopback (ranks share device 0)
 
     Mesh2D mesh = Mesh2D::uniform_rect(nx, -1.0, 1.0, nx, -1.0, 1.0);
     Basis basis(nb);

@@ -49,10 +49,12 @@ namespace cuddh
 
     /// The flow of examples/DDH.cpp:141-144 (rhs -> gmres -> postprocess) on `world` devices of this process: uniform_rect
     /// (nx x nx on [-1,1]^2), Basis(nb), h_a nodal coefficient (HOST, global numbering), h_f = [f; g] load vector (HOST,
-    /// 2 ndof), h_u receives [u; v] (HOST, 2 ndof).  world = 1 runs without communicator unless force_rccl is set (then the
-    /// one-rank communicator carries the reductions: exercises the RCCL path on a one-GPU box).
+    /// 2 ndof), h_u receives [u; v] (HOST, 2 ndof).  transport: 0 = RCCL for world > 1, no communicator for world = 1;
+    /// 1 = RCCL also for world = 1 (the one-rank communicator carries the reductions: exercises the RCCL calls on a one-GPU
+    /// box); 2 = loopback: the `world` ranks are host threads SHARING device 0, messages are device-to-device copies and
+    /// reductions host sums in rank order -- a test transport that runs the whole N > 1 path except the RCCL calls on one GPU.
     multi_gpu_result ddh_solve_multi_gpu(int nx, int nb, double omega, const double *h_a, const double *h_f, double *h_u, int world,
-                                         int gmres_m, int gmres_maxit, float tol, bool force_rccl = false);
+                                         int gmres_m, int gmres_maxit, float tol, int transport = 0);
 } // namespace cuddh
 
 #endif

@@ -10,6 +10,7 @@
 #include <chrono>
 #include <cstring>
 #include <exception>
+#include <condition_variable>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -140,10 +141,40 @@ namespace cuddh
         using clk = std::chrono::steady_clock;
         double since(clk::time_point t) { return std::chrono::duration<double>(clk::now() - t).count(); }
 
+        // Loopback transport (transport == 2): the ranks are host threads that SHARE one device, messages are device-to-device
+        // copies between their buffers and reductions are summed on the host in rank order.  It carries no performance claim;
+        // it exists so that everything of the N > 1 path except the RCCL calls themselves -- exchange plan, pack / unpack,
+        // partitioned Krylov vectors, the reduce hook, one stream per thread -- runs on a one-GPU box (tests).
+        struct Loopback
+        {
+            explicit Loopback(int world) : n(world), box(static_cast<std::size_t>(world) * world, nullptr), vals(world) {}
+            void barrier()
+            {
+                std::unique_lock<std::mutex> lk(m);
+                const long gen = generation;
+                if (++arrived == n)
+                {
+                    arrived = 0;
+                    ++generation;
+                    cv.notify_all();
+                }
+                else
+                    cv.wait(lk, [&] { return generation != gen; });
+            }
+            int n;
+            std::vector<const float *> box; // box[from * n + to]: device pointer of the message from -> to
+            std::vector<std::vector<double>> vals;
+            std::mutex m;
+            std::condition_variable cv;
+            int arrived = 0;
+            long generation = 0;
+        };
+
         // everything one device needs, built and used by that device's host thread only
         struct Rank
         {
             int rank, world, device;
+            Loopback *loop = nullptr;  // test transport, see above
             ncclComm_t comm = nullptr; // null: no communicator (world == 1 without force_rccl)
             hipStream_t st = nullptr;
             std::unique_ptr<Mesh2D> mesh;
@@ -171,6 +202,23 @@ namespace cuddh
                     detail::check_hip(cuddh_hip_trace_pack_f32(cnt, n_half, kv.second.device_read(), out, sbuf[kv.first].device_write(), 1, st),
                                       "trace pack");
                 }
+                if (loop)
+                {
+                    sync(); // my messages are packed
+                    for (auto &kv : send_slots)
+                        loop->box[static_cast<std::size_t>(rank) * world + kv.first] = sbuf[kv.first].device_read();
+                    loop->barrier();
+                    for (auto &kv : recv_slots)
+                        detail::check_hip(static_cast<int>(hipMemcpyAsync(rbuf[kv.first].device_write(), loop->box[static_cast<std::size_t>(kv.first) * world + rank],
+                                                                            sizeof(float) * 2 * kv.second.size(), hipMemcpyDeviceToDevice, st)),
+                                          "loopback message");
+                    sync();
+                    loop->barrier(); // every message is delivered: the send buffers may be reused
+                    for (auto &kv : recv_slots)
+                        detail::check_hip(cuddh_hip_trace_unpack_f32(kv.second.size(), n_half, kv.second.device_read(), rbuf[kv.first].device_read(), out, st),
+                                          "trace unpack");
+                    return;
+                }
                 check_nccl(Rccl::get().GroupStart(), "ncclGroupStart");
                 for (int peer = 0; peer < world; ++peer)
                 {
@@ -189,6 +237,31 @@ namespace cuddh
 
             void all_reduce(void *d, size_t count, ncclDataType_t type) const
             {
+                if (loop)
+                {
+                    const size_t bytes = count * (type == ncclDouble ? 8 : 4);
+                    std::vector<char> mine(bytes);
+                    detail::check_hip(cuddh_hip_copy_d2h_on(mine.data(), d, bytes, st), "loopback reduce");
+                    sync();
+                    std::vector<double> &slot = loop->vals[rank];
+                    slot.resize(count);
+                    for (size_t i = 0; i < count; ++i)
+                        slot[i] = type == ncclDouble ? reinterpret_cast<const double *>(mine.data())[i] : reinterpret_cast<const float *>(mine.data())[i];
+                    loop->barrier();
+                    std::vector<double> sum(count, 0.0);
+                    for (int r = 0; r < world; ++r) // rank order: every rank gets the same bits
+                        for (size_t i = 0; i < count; ++i)
+                            sum[i] += loop->vals[r][i];
+                    loop->barrier(); // everybody has read the slots
+                    for (size_t i = 0; i < count; ++i)
+                        if (type == ncclDouble)
+                            reinterpret_cast<double *>(mine.data())[i] = sum[i];
+                        else
+                            reinterpret_cast<float *>(mine.data())[i] = static_cast<float>(sum[i]);
+                    detail::check_hip(cuddh_hip_copy_h2d_on(d, mine.data(), bytes, st), "loopback reduce");
+                    sync();
+                    return;
+                }
                 if (comm)
                     check_nccl(Rccl::get().AllReduce(d, d, count, type, ncclSum, comm, st), "ncclAllReduce");
             }
@@ -216,13 +289,15 @@ namespace cuddh
     } // namespace
 
     multi_gpu_result ddh_solve_multi_gpu(int nx, int nb, double omega, const double *h_a, const double *h_f, double *h_u, int world,
-                                         int gmres_m, int gmres_maxit, float tol, bool force_rccl)
+                                         int gmres_m, int gmres_maxit, float tol, int transport)
     {
         int n_dev = 0;
         detail::check_hip(static_cast<int>(hipGetDeviceCount(&n_dev)), "hipGetDeviceCount");
-        if (world < 1 || world > n_dev)
+        const bool loopback = transport == 2;
+        if (world < 1 || (!loopback && world > n_dev) || world > 64)
             cuddh_error("ddh_solve_multi_gpu error: need 1 <= world <= number of visible devices (one rank per GPU).");
-        const bool use_rccl = world > 1 || force_rccl;
+        const bool use_rccl = !loopback && (world > 1 || transport == 1);
+        Loopback loop_state(world);
 
         std::vector<ncclComm_t> comms(world, nullptr);
         if (use_rccl)
@@ -245,12 +320,13 @@ namespace cuddh
         {
             try
             {
-                detail::check_hip(static_cast<int>(hipSetDevice(rank)), "hipSetDevice");
+                detail::check_hip(static_cast<int>(hipSetDevice(loopback ? 0 : rank)), "hipSetDevice");
                 Rank R;
                 R.rank = rank;
                 R.world = world;
-                R.device = rank;
+                R.device = loopback ? 0 : rank;
                 R.comm = comms[rank];
+                R.loop = (loopback && world > 1) ? &loop_state : nullptr;
                 detail::check_hip(static_cast<int>(hipStreamCreateWithFlags(&R.st, hipStreamNonBlocking)), "hipStreamCreate");
                 set_stream(R.st); // thread-local: this thread's launches go to this device's stream
 
@@ -298,7 +374,7 @@ namespace cuddh
                 ShardOperator A(R);
                 const ScalarReduce red{reduce_hook, &R};
                 t0 = clk::now();
-                outs[rank] = use_rccl ? gmres(n, d_lam, &A, d_b, gmres_m, gmres_maxit, tol, 0, 6 * 60 * 60.0, red)
+                outs[rank] = (use_rccl || R.loop) ? gmres(n, d_lam, &A, d_b, gmres_m, gmres_maxit, tol, 0, 6 * 60 * 60.0, red)
                                       : gmres(n, d_lam, &A, d_b, gmres_m, gmres_maxit, tol, 0);
                 R.sync();
                 t_gmres[rank] = since(t0);

@@ -100,9 +100,11 @@ def native_trace_exchange(B, n_domains: int, mx_fdof: int, n_lambda: int, rank: 
 
 
 def ddh_solve_multi_gpu(nx: int, nb: int, omega: float, h_a, h_f, world: int, m: int = 20, maxit: int = 100, tol: float = 1e-4,
-                        force_rccl: bool = False):
+                        force_rccl=False):
     """rhs -> gmres -> postprocess on `world` GPUs of this process through the C++ host (cuddh::ddh_solve_multi_gpu: one
-    host thread per device, RCCL send/recv for the traces, ncclAllReduce for the inner products).  Host arrays in, (u, info) out."""
+    host thread per device, RCCL send/recv for the traces, ncclAllReduce for the inner products).  Host arrays in, (u, info) out.
+    force_rccl: False / 0 auto, True / 1 RCCL also for one rank, 2 the loopback test transport (the ranks are threads sharing
+    device 0: everything of the N > 1 path except the RCCL calls, on a one-GPU box)."""
     import ctypes as C
 
     import numpy as np

@@ -201,6 +201,45 @@ def test_helmholtz_solve_driver(cuda, tmp_path):
     assert out.res_norm[-1] < out.res_norm[0]
 
 
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_multi_gpu_host_loopback_ranks(cuda, world):
+    """cuddh::ddh_solve_multi_gpu with its loopback transport: `world` ranks as host threads sharing the test GPU (one stream
+    each), messages as device-to-device copies, reductions summed on the host in rank order.  Everything of the C++ N > 1
+    path runs -- TraceExchangePlan, trace pack / unpack, partitioned Krylov vectors, the GMRES reduce hook, the final sum of u
+    -- except the RCCL calls themselves (those run with one rank in test_multi_gpu_host_one_rank).  The traces are copied,
+    never summed, so the iteration is the single-process one up to the order of the inner-product sums."""
+    import torch
+
+    import cuddhelmholtz_amd as cd
+    from cuddhelmholtz_amd.dist import ddh_solve_multi_gpu
+
+    nx, nb = 32, 4
+    omega = 2 * math.pi * nx / 10
+    fem = cd.H1Space(cd.Mesh2D.uniform_rect(nx, -1.0, 1.0, nx, -1.0, 1.0), cd.Basis(nb))
+    n = fem.size()
+    f = torch.zeros(2 * n, dtype=torch.float64, device=cuda)
+    a = torch.zeros(n, dtype=torch.float64, device=cuda)
+    cd.linear_functional(fem, cd.GAUSSIANS, f[:n], param=omega)
+    cd.linear_functional(fem, cd.ALPHA_DISK, a)
+    cd.DiagInvMassMatrix(fem).action(a, a)
+    h_a, h_f = a.cpu().numpy(), f.cpu().numpy()
+    F = cd.DDH(omega, h_a, fem, nx, nx)
+    b = torch.zeros(F.size(), dtype=torch.float32, device=cuda)
+    lam = torch.zeros_like(b)
+    u = torch.zeros_like(f)
+    F.rhs(f, b)
+    out = cd.gmres(F.size(), lam, F, b, 20, 100, 1e-4)
+    F.postprocess(lam, f, u)
+    u_multi, info = ddh_solve_multi_gpu(nx, nb, omega, h_a, h_f, world=world, m=20, maxit=100, tol=1e-4, force_rccl=2)
+    cd.use_torch_stream()
+    assert info["world"] == world and not info["used_rccl"] and info["success"] == int(out.success) == 1
+    assert info["bytes_sent_per_action_rank0"] > 0
+    assert abs(info["num_matvec"] - out.num_matvec) <= 2
+    err = float(np.linalg.norm(u_multi - u.cpu().numpy()) / np.linalg.norm(u.cpu().numpy()))
+    print(f"multi-GPU host, {world} loopback ranks: {info['num_matvec']} matvecs (plain {out.num_matvec}), u vs plain solve {err:.2e}")
+    assert err < 1e-3
+
+
 @pytest.mark.parametrize("force_rccl", [False, True])
 def test_multi_gpu_host_one_rank(cuda, force_rccl):
     """cuddh::ddh_solve_multi_gpu (one process, one host thread and one stream per device, RCCL) with the single device of
