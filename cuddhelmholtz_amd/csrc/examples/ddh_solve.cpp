@@ -4,7 +4,7 @@
 // Writes <out_dir>/xy.0000 and <out_dir>/ddh.0000 (raw fp64, like the reference) and prints one summary line.
 // devices >= 1: the same solve through cuddh::ddh_solve_multi_gpu (multigpu.hpp): subdomains sharded over that many GPUs of
 // this process, RCCL neighbour exchange; devices = 1 with force_rccl = 1 runs the communicator path on a one-GPU box;
-// force_rccl = 2 is the loopback test transport (the ranks share device 0, no RCCL).
+// force_rccl = 2 is the loopback test transport (the ranks share device 0, no RCCL); + 4 selects the split schedule.
 #include <chrono>
 #include <cstdlib>
 #include <string>
@@ -51,7 +51,8 @@ int main(int argc, char **argv)
     if (devices >= 1)
     {
         std::vector<double> h_u(N);
-        const multi_gpu_result r = ddh_solve_multi_gpu(nx, nb, omega, a.host_read(), b.host_read(), h_u.data(), devices, m, maxit, tol, force_rccl);
+        const multi_gpu_result r = ddh_solve_multi_gpu(nx, nb, omega, a.host_read(), b.host_read(), h_u.data(), devices, m, maxit, tol, force_rccl & 3,
+                                                       (force_rccl & 4) != 0);
         if (out_dir != "-")
         {
             to_file(out_dir + "/xy.0000", N, fem.physical_coordinates(MemorySpace::HOST));

@@ -34,6 +34,9 @@ namespace cuddh
         std::vector<int> owned;                // slots this rank owns, increasing
         std::map<int, std::vector<int>> send;  // peer -> slots this rank's subdomains write and the peer owns, increasing
         std::map<int, std::vector<int>> recv;  // peer -> slots this rank owns and the peer's subdomains write, increasing
+        /// split schedule: the subdomains whose traces other ranks wait for (plus up to 7 others, so that both launches consist
+        /// of whole workgroups of the wavefront kernels) and the rest of [dom_begin, dom_end); both increasing
+        std::vector<int> boundary, interior;
 
         static TraceExchangePlan build(const int *B, int n_domains, int mx_fdof, int n_lambda, int rank, int world);
     };
@@ -53,8 +56,11 @@ namespace cuddh
     /// 1 = RCCL also for world = 1 (the one-rank communicator carries the reductions: exercises the RCCL calls on a one-GPU
     /// box); 2 = loopback: the `world` ranks are host threads SHARING device 0, messages are device-to-device copies and
     /// reductions host sums in rank order -- a test transport that runs the whole N > 1 path except the RCCL calls on one GPU.
+    /// split_schedule: the boundary subdomains are solved first, as one listed launch with issue priority on a second stream,
+    /// the exchange is posted behind them and the interior subdomains run on the main stream meanwhile (the north star's
+    /// schedule; default: exchange after all local solves).
     multi_gpu_result ddh_solve_multi_gpu(int nx, int nb, double omega, const double *h_a, const double *h_f, double *h_u, int world,
-                                         int gmres_m, int gmres_maxit, float tol, int transport = 0);
+                                         int gmres_m, int gmres_maxit, float tol, int transport = 0, bool split_schedule = false);
 } // namespace cuddh
 
 #endif

@@ -625,7 +625,8 @@ extern "C"
     {
         return guarded([&]
         {
-            const multi_gpu_result r = ddh_solve_multi_gpu(nx, nb, omega, h_a, h_f, h_u, world, m, maxit, static_cast<float>(tol), force_rccl);
+            const multi_gpu_result r = ddh_solve_multi_gpu(nx, nb, omega, h_a, h_f, h_u, world, m, maxit, static_cast<float>(tol), force_rccl & 3,
+                                                           (force_rccl & 4) != 0);
             out->success = r.gmres.success ? 1 : 0;
             out->num_iter = r.gmres.num_iter;
             out->num_matvec = r.gmres.num_matvec;
@@ -652,6 +653,10 @@ extern "C"
             static const std::vector<int> none;
             if (which == 0)
                 v = &p.owned;
+            else if (which == 3)
+                v = &p.boundary;
+            else if (which == 4)
+                v = &p.interior;
             else
             {
                 const auto &m = which == 1 ? p.send : p.recv;

@@ -69,6 +69,20 @@ namespace cuddh
             else if (owner >= 0 && wrank == rank)
                 p.send[owner].push_back(t);
         }
+        // boundary subdomains = writers of the slots that are sent
+        std::vector<char> is_boundary(n_domains, 0);
+        for (const auto &kv : p.send)
+            for (const int t : kv.second)
+                is_boundary[writer[t]] = 1;
+        for (int s = p.dom_begin; s < p.dom_end; ++s)
+            (is_boundary[s] ? p.boundary : p.interior).push_back(s);
+        if (!p.boundary.empty())
+        {
+            const std::size_t pad = std::min<std::size_t>((8 - p.boundary.size() % 8) % 8, p.interior.size());
+            p.boundary.insert(p.boundary.end(), p.interior.begin(), p.interior.begin() + pad);
+            p.interior.erase(p.interior.begin(), p.interior.begin() + pad);
+            std::sort(p.boundary.begin(), p.boundary.end());
+        }
         return p;
     }
 
@@ -177,6 +191,9 @@ namespace cuddh
             Loopback *loop = nullptr;  // test transport, see above
             ncclComm_t comm = nullptr; // null: no communicator (world == 1 without force_rccl)
             hipStream_t st = nullptr;
+            hipStream_t st_side = nullptr; // split schedule: boundary subdomains and the exchange
+            hipEvent_t ev_main = nullptr, ev_side = nullptr;
+            HostDeviceArray<int> boundary_ids, interior_ids;
             std::unique_ptr<Mesh2D> mesh;
             std::unique_ptr<Basis> basis;
             std::unique_ptr<H1Space> fem;
@@ -192,30 +209,62 @@ namespace cuddh
             {
                 const int n = F->size();
                 detail::check_hip(cuddh_hip_memset_zero(out, sizeof(float) * n, st), "trace zero fill");
-                F->local_traces(plan.dom_begin, plan.dom_end, f, lambda, out);
+                const bool split = st_side && world > 1 && boundary_ids.size() > 0;
+                hipStream_t xst = st; // the stream the exchange runs on
+                if (!split)
+                    F->local_traces(plan.dom_begin, plan.dom_end, f, lambda, out);
+                else
+                {
+                    // boundary subdomains: one listed launch with issue priority on the side stream, the exchange behind it;
+                    // the interior on the main stream meanwhile (dist.py::NeighbourShardedDDH.traces, profiles/r02/overlap_timeline.txt)
+                    const auto &core = F->internals();
+                    detail::check_hip(static_cast<int>(hipEventRecord(ev_main, st)), "event record");
+                    detail::check_hip(static_cast<int>(hipStreamWaitEvent(st_side, ev_main, 0)), "stream wait");
+                    set_stream(st_side);
+                    core.set_wave_priority(true);
+                    core.solve_listed(boundary_ids.device_read(), boundary_ids.size(), f, lambda, out);
+                    core.set_wave_priority(false);
+                    set_stream(st);
+                    if (interior_ids.size() > 0)
+                        core.solve_listed(interior_ids.device_read(), interior_ids.size(), f, lambda, out);
+                    xst = st_side;
+                }
                 if (world == 1)
                     return;
                 const int n_half = n / 2; // = 2 n_shared: lambda half and mu half of a trace vector
+                struct Join // the main stream continues after the exchange on the side stream
+                {
+                    Rank &r;
+                    bool on;
+                    ~Join()
+                    {
+                        if (on)
+                        {
+                            (void)hipEventRecord(r.ev_side, r.st_side);
+                            (void)hipStreamWaitEvent(r.st, r.ev_side, 0);
+                        }
+                    }
+                } join{*this, split};
                 for (auto &kv : send_slots)
                 {
                     const int cnt = kv.second.size();
-                    detail::check_hip(cuddh_hip_trace_pack_f32(cnt, n_half, kv.second.device_read(), out, sbuf[kv.first].device_write(), 1, st),
+                    detail::check_hip(cuddh_hip_trace_pack_f32(cnt, n_half, kv.second.device_read(), out, sbuf[kv.first].device_write(), 1, xst),
                                       "trace pack");
                 }
                 if (loop)
                 {
-                    sync(); // my messages are packed
+                    detail::check_hip(cuddh_hip_stream_sync(xst), "stream sync"); // my messages are packed
                     for (auto &kv : send_slots)
                         loop->box[static_cast<std::size_t>(rank) * world + kv.first] = sbuf[kv.first].device_read();
                     loop->barrier();
                     for (auto &kv : recv_slots)
                         detail::check_hip(static_cast<int>(hipMemcpyAsync(rbuf[kv.first].device_write(), loop->box[static_cast<std::size_t>(kv.first) * world + rank],
-                                                                            sizeof(float) * 2 * kv.second.size(), hipMemcpyDeviceToDevice, st)),
+                                                                            sizeof(float) * 2 * kv.second.size(), hipMemcpyDeviceToDevice, xst)),
                                           "loopback message");
-                    sync();
+                    detail::check_hip(cuddh_hip_stream_sync(xst), "stream sync");
                     loop->barrier(); // every message is delivered: the send buffers may be reused
                     for (auto &kv : recv_slots)
-                        detail::check_hip(cuddh_hip_trace_unpack_f32(kv.second.size(), n_half, kv.second.device_read(), rbuf[kv.first].device_read(), out, st),
+                        detail::check_hip(cuddh_hip_trace_unpack_f32(kv.second.size(), n_half, kv.second.device_read(), rbuf[kv.first].device_read(), out, xst),
                                           "trace unpack");
                     return;
                 }
@@ -224,14 +273,14 @@ namespace cuddh
                 {
                     auto s = send_slots.find(peer);
                     if (s != send_slots.end())
-                        check_nccl(Rccl::get().Send(sbuf[peer].device_read(), 2 * static_cast<size_t>(s->second.size()), ncclFloat, peer, comm, st), "ncclSend");
+                        check_nccl(Rccl::get().Send(sbuf[peer].device_read(), 2 * static_cast<size_t>(s->second.size()), ncclFloat, peer, comm, xst), "ncclSend");
                     auto r = recv_slots.find(peer);
                     if (r != recv_slots.end())
-                        check_nccl(Rccl::get().Recv(rbuf[peer].device_write(), 2 * static_cast<size_t>(r->second.size()), ncclFloat, peer, comm, st), "ncclRecv");
+                        check_nccl(Rccl::get().Recv(rbuf[peer].device_write(), 2 * static_cast<size_t>(r->second.size()), ncclFloat, peer, comm, xst), "ncclRecv");
                 }
                 check_nccl(Rccl::get().GroupEnd(), "ncclGroupEnd");
                 for (auto &kv : recv_slots)
-                    detail::check_hip(cuddh_hip_trace_unpack_f32(kv.second.size(), n_half, kv.second.device_read(), rbuf[kv.first].device_read(), out, st),
+                    detail::check_hip(cuddh_hip_trace_unpack_f32(kv.second.size(), n_half, kv.second.device_read(), rbuf[kv.first].device_read(), out, xst),
                                       "trace unpack");
             }
 
@@ -289,7 +338,7 @@ namespace cuddh
     } // namespace
 
     multi_gpu_result ddh_solve_multi_gpu(int nx, int nb, double omega, const double *h_a, const double *h_f, double *h_u, int world,
-                                         int gmres_m, int gmres_maxit, float tol, int transport)
+                                         int gmres_m, int gmres_maxit, float tol, int transport, bool split_schedule)
     {
         int n_dev = 0;
         detail::check_hip(static_cast<int>(hipGetDeviceCount(&n_dev)), "hipGetDeviceCount");
@@ -357,6 +406,14 @@ namespace cuddh
                 if (rank == 0)
                     for (const auto &kv : R.plan.send)
                         res.bytes_sent_per_action_rank0 += 2LL * kv.second.size() * sizeof(float);
+                if (split_schedule && world > 1)
+                {
+                    detail::check_hip(static_cast<int>(hipStreamCreateWithFlags(&R.st_side, hipStreamNonBlocking)), "hipStreamCreate");
+                    detail::check_hip(static_cast<int>(hipEventCreateWithFlags(&R.ev_main, hipEventDisableTiming)), "hipEventCreate");
+                    detail::check_hip(static_cast<int>(hipEventCreateWithFlags(&R.ev_side, hipEventDisableTiming)), "hipEventCreate");
+                    upload(R.plan.boundary, R.boundary_ids);
+                    upload(R.plan.interior, R.interior_ids);
+                }
 
                 host_device_dvec f(2 * ndof), u(2 * ndof);
                 std::memcpy(f.host_write(), h_f, sizeof(double) * 2 * ndof);
@@ -393,6 +450,13 @@ namespace cuddh
                 R.F.reset();
                 R.fem.reset();
                 set_stream(nullptr);
+                if (R.st_side)
+                {
+                    (void)hipStreamSynchronize(R.st_side);
+                    (void)hipEventDestroy(R.ev_main);
+                    (void)hipEventDestroy(R.ev_side);
+                    (void)hipStreamDestroy(R.st_side);
+                }
                 (void)hipStreamDestroy(R.st);
             }
             catch (...)

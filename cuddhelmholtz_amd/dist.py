@@ -93,6 +93,7 @@ def native_trace_exchange(B, n_domains: int, mx_fdof: int, n_lambda: int, rank: 
             lib.cuddh_trace_exchange_query(pB, n_domains, mx_fdof, n_lambda, rank, world, which, peer, out.ctypes.data_as(C.c_void_p))
         return out
 
+    native_trace_exchange.last_split = (query(3, 0), query(4, 0))  # subdomains of the boundary / interior launch (split schedule)
     owned = query(0, 0)
     send = {p: a for p in range(world) if p != rank and (a := query(1, p)).size}
     recv = {p: a for p in range(world) if p != rank and (a := query(2, p)).size}
@@ -100,11 +101,12 @@ def native_trace_exchange(B, n_domains: int, mx_fdof: int, n_lambda: int, rank: 
 
 
 def ddh_solve_multi_gpu(nx: int, nb: int, omega: float, h_a, h_f, world: int, m: int = 20, maxit: int = 100, tol: float = 1e-4,
-                        force_rccl=False):
+                        force_rccl=False, split_schedule: bool = False):
     """rhs -> gmres -> postprocess on `world` GPUs of this process through the C++ host (cuddh::ddh_solve_multi_gpu: one
     host thread per device, RCCL send/recv for the traces, ncclAllReduce for the inner products).  Host arrays in, (u, info) out.
     force_rccl: False / 0 auto, True / 1 RCCL also for one rank, 2 the loopback test transport (the ranks are threads sharing
-    device 0: everything of the N > 1 path except the RCCL calls, on a one-GPU box)."""
+    device 0: everything of the N > 1 path except the RCCL calls, on a one-GPU box).  split_schedule: boundary subdomains first
+    (one listed launch with issue priority on a second stream), exchange behind them, interior meanwhile."""
     import ctypes as C
 
     import numpy as np
@@ -117,7 +119,7 @@ def ddh_solve_multi_gpu(nx: int, nb: int, omega: float, h_a, h_f, world: int, m:
     res = N.MultiGpuResult()
     hist = np.zeros(maxit + 2)
     vp = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
-    N.check_capi(N.lib.cuddh_ddh_solve_multi_gpu(nx, nb, float(omega), vp(h_a), vp(h_f), vp(u), world, m, maxit, float(tol), int(force_rccl),
+    N.check_capi(N.lib.cuddh_ddh_solve_multi_gpu(nx, nb, float(omega), vp(h_a), vp(h_f), vp(u), world, m, maxit, float(tol), int(force_rccl) | (4 if split_schedule else 0),
                                                 C.byref(res), vp(hist)), "ddh_solve_multi_gpu")
     info = {k: getattr(res, k) for k, _ in N.MultiGpuResult._fields_}
     info["res_norm"] = hist[: res.n_res].tolist()

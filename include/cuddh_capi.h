@@ -121,11 +121,15 @@ typedef struct cuddh_multi_gpu_result
     long long bytes_sent_per_action_rank0;
 } cuddh_multi_gpu_result;
 /* rhs -> gmres -> postprocess of examples/DDH.cpp:141-144 on uniform_rect(nx), Basis(nb), fp32 DDH, `world` devices.
- * h_a (ndof), h_f (2 ndof), h_u (2 ndof) HOST in the global numbering; h_res (maxit + 2) receives the residual history. */
+ * h_a (ndof), h_f (2 ndof), h_u (2 ndof) HOST in the global numbering; h_res (maxit + 2) receives the residual history.
+ * force_rccl: bits 0-1 = transport (0 RCCL for world > 1, 1 RCCL also for one rank, 2 loopback: ranks are threads sharing
+ * device 0, a test transport), bit 2 (value 4) = split schedule (boundary subdomains first on a second stream with issue
+ * priority, exchange behind them, interior meanwhile); csrc/include/cuddh/multigpu.hpp. */
 int cuddh_ddh_solve_multi_gpu(int nx, int nb, double omega, const double *h_a, const double *h_f, double *h_u, int world, int m,
                               int maxit, double tol, int force_rccl, cuddh_multi_gpu_result *out, double *h_res);
 /* ownership / send / receive lists of the trace exchange for `rank` of `world` (host only; what both the C++ and the
- * Python multi-GPU hosts use).  which: 0 owned slots, 1 slots sent to `peer`, 2 slots received from `peer`.  Returns the
+ * Python multi-GPU hosts use).  which: 0 owned slots, 1 slots sent to `peer`, 2 slots received from `peer`, 3 / 4 the subdomains
+ * of the boundary / interior launch of the split schedule.  Returns the
  * count (-1 on error); h_out may be NULL to ask for the count only.  h_B: (mx_fdof, 2, n_domains). */
 int cuddh_trace_exchange_query(const int *h_B, int n_domains, int mx_fdof, int n_lambda, int rank, int world, int which, int peer,
                                int *h_out);

@@ -353,3 +353,17 @@ def test_native_trace_exchange_plan_equals_python(nx, nb, world):
             assert np.array_equal(send[p], ex.send_slots[p])
         for p in recv:
             assert np.array_equal(recv[p], ex.recv_slots[p])
+        # the two launches of the split schedule: the same subdomains in both hosts (boundary padded to whole workgroups)
+        from cuddhelmholtz_amd.dist import NeighbourShardedDDH
+
+        class _Engine:  # what NeighbourShardedDDH asks of an engine at construction
+            def table(self, name):
+                return B
+
+            def info(self):
+                return info
+
+        sh = NeighbourShardedDDH(_Engine(), info["n_domains"], rank, world)
+        boundary, interior = native_trace_exchange.last_split
+        assert np.array_equal(boundary, sh._ids["boundary"]) and np.array_equal(interior, sh._ids["interior"])
+        assert boundary.size % 8 == 0 or interior.size == 0 or world == 1
