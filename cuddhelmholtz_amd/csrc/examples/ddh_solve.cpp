@@ -52,7 +52,7 @@ int main(int argc, char **argv)
     {
         std::vector<double> h_u(N);
         const multi_gpu_result r = ddh_solve_multi_gpu(nx, nb, omega, a.host_read(), b.host_read(), h_u.data(), devices, m, maxit, tol, force_rccl & 3,
-                                                       (force_rccl & 4) != 0);
+                                                       (force_rccl & 4) != 0, (force_rccl >> 8) & 0xFF, (force_rccl >> 16) & 0xFF);
         if (out_dir != "-")
         {
             to_file(out_dir + "/xy.0000", N, fem.physical_coordinates(MemorySpace::HOST));

@@ -37,8 +37,14 @@ namespace cuddh
         /// split schedule: the subdomains whose traces other ranks wait for (plus up to 7 others, so that both launches consist
         /// of whole workgroups of the wavefront kernels) and the rest of [dom_begin, dom_end); both increasing
         std::vector<int> boundary, interior;
+        /// this rank's subdomains, increasing ([dom_begin, dom_end) for strips; a rectangle's rows for a rank grid)
+        std::vector<int> domains;
 
-        static TraceExchangePlan build(const int *B, int n_domains, int mx_fdof, int n_lambda, int rank, int world);
+        /// dom_rank (n_domains, or null): subdomain -> rank; null = `world` contiguous ranges (strips of block rows)
+        static TraceExchangePlan build(const int *B, int n_domains, int mx_fdof, int n_lambda, int rank, int world,
+                                       const int *dom_rank = nullptr);
+        /// subdomain -> rank for a gx x gy grid of ranks over the ndx x ndy block grid (rank = rx + gx ry)
+        static std::vector<int> rank_grid(int ndx, int ndy, int gx, int gy);
     };
 
     struct multi_gpu_result
@@ -58,9 +64,11 @@ namespace cuddh
     /// reductions host sums in rank order -- a test transport that runs the whole N > 1 path except the RCCL calls on one GPU.
     /// split_schedule: the boundary subdomains are solved first, as one listed launch with issue priority on a second stream,
     /// the exchange is posted behind them and the interior subdomains run on the main stream meanwhile (the north star's
-    /// schedule; default: exchange after all local solves).
+    /// schedule; default: exchange after all local solves).  grid_x x grid_y = world: the ranks own rectangles of the
+    /// subdomain grid instead of strips of block rows (0: strips).
     multi_gpu_result ddh_solve_multi_gpu(int nx, int nb, double omega, const double *h_a, const double *h_f, double *h_u, int world,
-                                         int gmres_m, int gmres_maxit, float tol, int transport = 0, bool split_schedule = false);
+                                         int gmres_m, int gmres_maxit, float tol, int transport = 0, bool split_schedule = false,
+                                         int grid_x = 0, int grid_y = 0);
 } // namespace cuddh
 
 #endif

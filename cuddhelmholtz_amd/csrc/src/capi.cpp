@@ -626,7 +626,7 @@ extern "C"
         return guarded([&]
         {
             const multi_gpu_result r = ddh_solve_multi_gpu(nx, nb, omega, h_a, h_f, h_u, world, m, maxit, static_cast<float>(tol), force_rccl & 3,
-                                                           (force_rccl & 4) != 0);
+                                                           (force_rccl & 4) != 0, (force_rccl >> 8) & 0xFF, (force_rccl >> 16) & 0xFF);
             out->success = r.gmres.success ? 1 : 0;
             out->num_iter = r.gmres.num_iter;
             out->num_matvec = r.gmres.num_matvec;

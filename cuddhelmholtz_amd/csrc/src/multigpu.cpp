@@ -25,7 +25,20 @@
 
 namespace cuddh
 {
-    TraceExchangePlan TraceExchangePlan::build(const int *B, int n_domains, int mx_fdof, int n_lambda, int rank, int world)
+    std::vector<int> TraceExchangePlan::rank_grid(int ndx, int ndy, int gx, int gy)
+    {
+        if (gx < 1 || gy < 1 || gx > ndx || gy > ndy)
+            cuddh_error("TraceExchangePlan error: the rank grid does not fit the block grid.");
+        std::vector<int> out(static_cast<std::size_t>(ndx) * ndy);
+        for (int by = 0; by < ndy; ++by)
+            for (int bx = 0; bx < ndx; ++bx)
+                out[bx + static_cast<std::size_t>(ndx) * by] =
+                    static_cast<int>((static_cast<long long>(bx) * gx) / ndx) + gx * static_cast<int>((static_cast<long long>(by) * gy) / ndy);
+        return out;
+    }
+
+    TraceExchangePlan TraceExchangePlan::build(const int *B, int n_domains, int mx_fdof, int n_lambda, int rank, int world,
+                                               const int *given_dom_rank)
     {
         if (rank < 0 || rank >= world)
             cuddh_error("TraceExchangePlan error: rank out of range.");
@@ -36,11 +49,29 @@ namespace cuddh
         shard_range(n_domains, rank, world, p.dom_begin, p.dom_end);
 
         std::vector<int> dom_rank(n_domains);
-        for (int r = 0; r < world; ++r)
+        if (given_dom_rank)
         {
-            int a, b;
-            shard_range(n_domains, r, world, a, b);
-            std::fill(dom_rank.begin() + a, dom_rank.begin() + b, r);
+            for (int s = 0; s < n_domains; ++s)
+            {
+                if (given_dom_rank[s] < 0 || given_dom_rank[s] >= world)
+                    cuddh_error("TraceExchangePlan error: dom_rank needs one rank in [0, world) per subdomain.");
+                dom_rank[s] = given_dom_rank[s];
+            }
+        }
+        else
+            for (int r = 0; r < world; ++r)
+            {
+                int a, b;
+                shard_range(n_domains, r, world, a, b);
+                std::fill(dom_rank.begin() + a, dom_rank.begin() + b, r);
+            }
+        for (int s = 0; s < n_domains; ++s)
+            if (dom_rank[s] == rank)
+                p.domains.push_back(s);
+        if (given_dom_rank) // [dom_begin, dom_end) only spans this rank's subdomains; use `domains`
+        {
+            p.dom_begin = p.domains.empty() ? 0 : p.domains.front();
+            p.dom_end = p.domains.empty() ? 0 : p.domains.back() + 1;
         }
         std::vector<int> reader(n_lambda, -1), writer(n_lambda, -1);
         for (int s = 0; s < n_domains; ++s)
@@ -74,7 +105,7 @@ namespace cuddh
         for (const auto &kv : p.send)
             for (const int t : kv.second)
                 is_boundary[writer[t]] = 1;
-        for (int s = p.dom_begin; s < p.dom_end; ++s)
+        for (const int s : p.domains)
             (is_boundary[s] ? p.boundary : p.interior).push_back(s);
         if (!p.boundary.empty())
         {
@@ -193,7 +224,7 @@ namespace cuddh
             hipStream_t st = nullptr;
             hipStream_t st_side = nullptr; // split schedule: boundary subdomains and the exchange
             hipEvent_t ev_main = nullptr, ev_side = nullptr;
-            HostDeviceArray<int> boundary_ids, interior_ids;
+            HostDeviceArray<int> boundary_ids, interior_ids, all_ids; // all_ids: only when this rank's subdomains are not one range
             std::unique_ptr<Mesh2D> mesh;
             std::unique_ptr<Basis> basis;
             std::unique_ptr<H1Space> fem;
@@ -211,7 +242,9 @@ namespace cuddh
                 detail::check_hip(cuddh_hip_memset_zero(out, sizeof(float) * n, st), "trace zero fill");
                 const bool split = st_side && world > 1 && boundary_ids.size() > 0;
                 hipStream_t xst = st; // the stream the exchange runs on
-                if (!split)
+                if (!split && all_ids.size() > 0)
+                    F->internals().solve_listed(all_ids.device_read(), all_ids.size(), f, lambda, out);
+                else if (!split)
                     F->local_traces(plan.dom_begin, plan.dom_end, f, lambda, out);
                 else
                 {
@@ -338,8 +371,10 @@ namespace cuddh
     } // namespace
 
     multi_gpu_result ddh_solve_multi_gpu(int nx, int nb, double omega, const double *h_a, const double *h_f, double *h_u, int world,
-                                         int gmres_m, int gmres_maxit, float tol, int transport, bool split_schedule)
+                                         int gmres_m, int gmres_maxit, float tol, int transport, bool split_schedule, int grid_x, int grid_y)
     {
+        if ((grid_x != 0 || grid_y != 0) && grid_x * grid_y != world)
+            cuddh_error("ddh_solve_multi_gpu error: grid_x * grid_y must be the number of ranks.");
         int n_dev = 0;
         detail::check_hip(static_cast<int>(hipGetDeviceCount(&n_dev)), "hipGetDeviceCount");
         const bool loopback = transport == 2;
@@ -387,7 +422,14 @@ namespace cuddh
                 R.F.reset(new DDH(omega, h_a, *R.fem, nx, nx));
                 const auto &core = R.F->internals();
                 const int n = R.F->size();
-                R.plan = TraceExchangePlan::build(core.table_B().host_read(), core.num_domains(), core.max_fdof(), n / 2, rank, world);
+                std::vector<int> dom_rank;
+                if (grid_x > 0)
+                {
+                    const int ndx = nx / (16 / nb); // blocks of 16 / n_basis elements per side (source/DDH.cpp:336)
+                    dom_rank = TraceExchangePlan::rank_grid(ndx, core.num_domains() / ndx, grid_x, grid_y);
+                }
+                R.plan = TraceExchangePlan::build(core.table_B().host_read(), core.num_domains(), core.max_fdof(), n / 2, rank, world,
+                                                  dom_rank.empty() ? nullptr : dom_rank.data());
                 auto upload = [](const std::vector<int> &v, HostDeviceArray<int> &dst)
                 {
                     dst.resize(static_cast<int>(v.size()));
@@ -406,6 +448,9 @@ namespace cuddh
                 if (rank == 0)
                     for (const auto &kv : R.plan.send)
                         res.bytes_sent_per_action_rank0 += 2LL * kv.second.size() * sizeof(float);
+                const bool one_range = static_cast<int>(R.plan.domains.size()) == R.plan.dom_end - R.plan.dom_begin;
+                if (!one_range)
+                    upload(R.plan.domains, R.all_ids);
                 if (split_schedule && world > 1)
                 {
                     detail::check_hip(static_cast<int>(hipStreamCreateWithFlags(&R.st_side, hipStreamNonBlocking)), "hipStreamCreate");
@@ -438,7 +483,22 @@ namespace cuddh
 
                 t0 = clk::now();
                 double *d_u = u.device_write();
-                R.F->local_solution(R.plan.dom_begin, R.plan.dom_end, d_lam, d_f, d_u, true);
+                // (once per solve: run by run when the rank's subdomains are a rectangle of the block grid)
+                {
+                    bool first = true;
+                    const std::vector<int> &dm = R.plan.domains;
+                    for (std::size_t i = 0; i < dm.size();)
+                    {
+                        std::size_t j = i + 1;
+                        while (j < dm.size() && dm[j] == dm[j - 1] + 1)
+                            ++j;
+                        R.F->local_solution(dm[i], dm[j - 1] + 1, d_lam, d_f, d_u, first);
+                        first = false;
+                        i = j;
+                    }
+                    if (first) // a rank without subdomains still contributes zeros to the sum below
+                        detail::check_hip(cuddh_hip_memset_zero(d_u, sizeof(double) * 2 * ndof, R.st), "solution zero fill");
+                }
                 R.all_reduce(d_u, 2 * static_cast<size_t>(ndof), ncclDouble); // partition-of-unity sums cross the pieces
                 R.sync();
                 t_post[rank] = since(t0);

@@ -101,7 +101,7 @@ def native_trace_exchange(B, n_domains: int, mx_fdof: int, n_lambda: int, rank: 
 
 
 def ddh_solve_multi_gpu(nx: int, nb: int, omega: float, h_a, h_f, world: int, m: int = 20, maxit: int = 100, tol: float = 1e-4,
-                        force_rccl=False, split_schedule: bool = False):
+                        force_rccl=False, split_schedule: bool = False, rank_grid=None):
     """rhs -> gmres -> postprocess on `world` GPUs of this process through the C++ host (cuddh::ddh_solve_multi_gpu: one
     host thread per device, RCCL send/recv for the traces, ncclAllReduce for the inner products).  Host arrays in, (u, info) out.
     force_rccl: False / 0 auto, True / 1 RCCL also for one rank, 2 the loopback test transport (the ranks are threads sharing
@@ -119,7 +119,8 @@ def ddh_solve_multi_gpu(nx: int, nb: int, omega: float, h_a, h_f, world: int, m:
     res = N.MultiGpuResult()
     hist = np.zeros(maxit + 2)
     vp = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
-    N.check_capi(N.lib.cuddh_ddh_solve_multi_gpu(nx, nb, float(omega), vp(h_a), vp(h_f), vp(u), world, m, maxit, float(tol), int(force_rccl) | (4 if split_schedule else 0),
+    N.check_capi(N.lib.cuddh_ddh_solve_multi_gpu(nx, nb, float(omega), vp(h_a), vp(h_f), vp(u), world, m, maxit, float(tol),
+                                                int(force_rccl) | (4 if split_schedule else 0) | ((rank_grid[0] << 8) | (rank_grid[1] << 16) if rank_grid else 0),
                                                 C.byref(res), vp(hist)), "ddh_solve_multi_gpu")
     info = {k: getattr(res, k) for k, _ in N.MultiGpuResult._fields_}
     info["res_norm"] = hist[: res.n_res].tolist()

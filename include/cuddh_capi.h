@@ -124,7 +124,8 @@ typedef struct cuddh_multi_gpu_result
  * h_a (ndof), h_f (2 ndof), h_u (2 ndof) HOST in the global numbering; h_res (maxit + 2) receives the residual history.
  * force_rccl: bits 0-1 = transport (0 RCCL for world > 1, 1 RCCL also for one rank, 2 loopback: ranks are threads sharing
  * device 0, a test transport), bit 2 (value 4) = split schedule (boundary subdomains first on a second stream with issue
- * priority, exchange behind them, interior meanwhile); csrc/include/cuddh/multigpu.hpp. */
+ * priority, exchange behind them, interior meanwhile), bits 8-15 / 16-23 = gx / gy of a rank grid (gx gy = world: ranks own
+ * rectangles of the subdomain grid; 0 = strips of block rows); csrc/include/cuddh/multigpu.hpp. */
 int cuddh_ddh_solve_multi_gpu(int nx, int nb, double omega, const double *h_a, const double *h_f, double *h_u, int world, int m,
                               int maxit, double tol, int force_rccl, cuddh_multi_gpu_result *out, double *h_res);
 /* ownership / send / receive lists of the trace exchange for `rank` of `world` (host only; what both the C++ and the

@@ -201,15 +201,17 @@ def test_helmholtz_solve_driver(cuda, tmp_path):
     assert out.res_norm[-1] < out.res_norm[0]
 
 
-@pytest.mark.parametrize("world,split", [(2, False), (3, False), (4, False), (2, True), (4, True)])
-def test_multi_gpu_host_loopback_ranks(cuda, world, split):
+@pytest.mark.parametrize("world,split,grid", [(2, False, None), (3, False, None), (4, False, None), (2, True, None), (4, True, None),
+                                              (4, False, (2, 2)), (4, True, (2, 2)), (2, True, (2, 1))])
+def test_multi_gpu_host_loopback_ranks(cuda, world, split, grid):
     """cuddh::ddh_solve_multi_gpu with its loopback transport: `world` ranks as host threads sharing the test GPU (one stream
     each), messages as device-to-device copies, reductions summed on the host in rank order.  Everything of the C++ N > 1
     path runs -- TraceExchangePlan, trace pack / unpack, partitioned Krylov vectors, the GMRES reduce hook, the final sum of u
     -- except the RCCL calls themselves (those run with one rank in test_multi_gpu_host_one_rank).  The traces are copied,
     never summed, so the iteration is the single-process one up to the order of the inner-product sums.  split: the north
     star's schedule in the C++ host (boundary subdomains as one listed launch with issue priority on a second stream, exchange
-    behind them, interior on the main stream meanwhile)."""
+    behind them, interior on the main stream meanwhile).  grid: the ranks own rectangles of the subdomain grid (SURVEY 8e's
+    gx x gy; a rank's subdomains are then not one range: listed launches, cross points between four ranks)."""
     import torch
 
     import cuddhelmholtz_amd as cd
@@ -232,13 +234,13 @@ def test_multi_gpu_host_loopback_ranks(cuda, world, split):
     F.rhs(f, b)
     out = cd.gmres(F.size(), lam, F, b, 20, 100, 1e-4)
     F.postprocess(lam, f, u)
-    u_multi, info = ddh_solve_multi_gpu(nx, nb, omega, h_a, h_f, world=world, m=20, maxit=100, tol=1e-4, force_rccl=2, split_schedule=split)
+    u_multi, info = ddh_solve_multi_gpu(nx, nb, omega, h_a, h_f, world=world, m=20, maxit=100, tol=1e-4, force_rccl=2, split_schedule=split, rank_grid=grid)
     cd.use_torch_stream()
     assert info["world"] == world and not info["used_rccl"] and info["success"] == int(out.success) == 1
     assert info["bytes_sent_per_action_rank0"] > 0
     assert abs(info["num_matvec"] - out.num_matvec) <= 2
     err = float(np.linalg.norm(u_multi - u.cpu().numpy()) / np.linalg.norm(u.cpu().numpy()))
-    print(f"multi-GPU host, {world} loopback ranks, split schedule {split}: {info['num_matvec']} matvecs (plain {out.num_matvec}), u vs plain solve {err:.2e}")
+    print(f"multi-GPU host, {world} loopback ranks, split schedule {split}, grid {grid}: {info['num_matvec']} matvecs (plain {out.num_matvec}), u vs plain solve {err:.2e}")
     assert err < 1e-3
 
 
