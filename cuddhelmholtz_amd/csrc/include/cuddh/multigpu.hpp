@@ -1,5 +1,5 @@
-// DDH over the GPUs of one node from ONE process: the subdomain range is cut into `world` contiguous pieces,
-// one per device; every device runs its piece of the local solves on its own stream, the traces its subdomains write for
+// DDH over the GPUs of one node from ONE process: the subdomains are cut into `world` pieces -- contiguous ranges
+// (strips of block rows) or the rectangles of a gx x gy rank grid --, one per device; every device runs its piece of the local solves on its own stream, the traces its subdomains write for
 // subdomains of another piece travel by one grouped RCCL send/recv per action (ncclGroupStart / ncclSend / ncclRecv /
 // ncclGroupEnd over xGMI -- the neighbour all-to-all of the north star), and GMRES runs on partitioned trace vectors with
 // every inner product summed by ncclAllReduce through the ScalarReduce hook of krylov.hpp, so all devices take identical
