@@ -340,11 +340,12 @@ def main() -> None:
             "ddh_kernel": {1: "workgroup-per-subdomain", 2: "wavefront-per-subdomain", 3: "wavefront-per-subdomain, DPP-folded FMAs", 4: "wavefront-per-subdomain, DPP-folded FMAs + 4x4x1 MFMA", 5: "wavefront-per-subdomain, dense 16x16 element matrix on MFMA (v_mfma_f32_16x16x4_f32)", 6: "wavefront per two subdomains (n_basis 8), DPP-folded FMAs", 7: "wavefront per two subdomains (n_basis 8), separable sweep"}.get(info["kernel"], str(info["kernel"])),
             "sharding": {"none": "single GPU",
                          "allreduce": f"{world} contiguous subdomain ranges, replicated trace vectors, one RCCL all-reduce of the trace vector per step",
-                         "neighbour": f"{world} contiguous subdomain ranges, trace vectors partitioned by slot ownership, grouped RCCL "
+                         "neighbour": f"{world} " + ("rectangles of the subdomain grid" if args.rank_grid else "contiguous subdomain ranges")
+                                      + ", trace vectors partitioned by slot ownership, grouped RCCL "
                                       f"send/recv of {sum(i.numel() for i in getattr(sh, 'send_idx', {}).values()) * 4 / 1024:.0f} KiB to "
                                       f"{len(getattr(sh, 'send_idx', {}))} neighbour rank(s) per step (rank 0), all-reduce of each inner product"}[exchange]
                         + (", split schedule (boundary subdomains first with issue priority, exchange behind them)" if (args.overlap and exchange == "neighbour") else "")
-                        + (f", rank grid {args.rank_grid} (rectangles of the subdomain grid)" if (args.rank_grid and exchange == "neighbour") else "")
+                        + (f", rank grid {args.rank_grid}" if (args.rank_grid and exchange == "neighbour") else "")
                         + (f" [{exchange_note}]" if exchange_note else ""),
             "setup_seconds": round(t_constructors, 3),  # Mesh2D + H1Space + load vector / coefficient + DDH constructor + plan
             "rhs_and_exchange_check_seconds": round(t_setup - t_constructors, 3),  # DDH::rhs (one pass of local solves) [+ N > 1 start-up check]
