@@ -207,6 +207,12 @@ def test_trace_exchange_tables():
             assert doms == list(ex[r].domains) == list(np.flatnonzero(dr == r))
             assert (ex[r].d0 is None) == (gx > 1 and 16 // world > 4 // gx)  # one range only when a rank's rectangle is one block row
     assert np.array_equal(rank_grid_map(4, 4, 1, 2), [0] * 8 + [1] * 8)  # gx = 1: the strips `partition` gives
+    assert np.array_equal(rank_grid_map(5, 3, 2, 3).reshape(3, 5), [[0, 0, 0, 1, 1], [2, 2, 2, 3, 3], [4, 4, 4, 5, 5]])  # uneven split
+    for bad in ((0, 1), (5, 1), (1, 5)):
+        with pytest.raises(ValueError):
+            rank_grid_map(4, 4, *bad)
+    with pytest.raises(ValueError):
+        TraceExchange(B, t.n_domains, t.mx_fdof, t.n_lambda, 0, 2, np.full(t.n_domains, 2))  # a rank outside [0, world)
 
 
 @pytest.mark.parametrize("world,overlap,grid", [(2, False, None), (3, True, None), (4, True, (2, 2)), (2, False, (2, 1))])
