@@ -232,6 +232,7 @@ _sig("cuddh_ddh_postprocess", ci, vp, vp, vp, vp)
 _sig("cuddh_ddh_action", ci, vp, vp, vp)
 _sig("cuddh_ddh_local_traces", ci, vp, ci, ci, vp, vp, vp)
 _sig("cuddh_ddh_local_traces_listed", ci, vp, vp, ci, vp, vp, vp)
+_sig("cuddh_ddh_local_solution_listed", ci, vp, vp, ci, vp, vp, vp, ci)
 _sig("cuddh_ddh_local_solution", ci, vp, ci, ci, vp, vp, vp, ci)
 _sig("cuddh_ddh_table", C.c_longlong, vp, cp, vp, ci)
 _sig("cuddh_gmres_f64", ci, ci, vp, vp, vp, vp, ci, ci, cd, ci, cd, C.POINTER(SolverResult), vp, vp)

@@ -456,6 +456,12 @@ class DDH:
                                                         _ptr(f, "f64", 2 * self.fem.size(), "f"), _ptr(lam, self.trace_dtype, self.size(), "lambda"),
                                                         _ptr(update, self.trace_dtype, self.size(), "update")), "DDH.local_traces_listed")
 
+    def local_solution_listed(self, domains, lam, f, u, zero_u=True):
+        """local_solution for the subdomains listed in `domains` (int32 device tensor, distinct ids), one launch"""
+        N.check_capi(lib.cuddh_ddh_local_solution_listed(self._h, _ptr(domains, "i32", domains.numel(), "domains"), int(domains.numel()),
+                                                          _ptr(lam, self.trace_dtype, self.size(), "lambda"), _ptr(f, "f64", 2 * self.fem.size(), "f"),
+                                                          _ptr(u, "f64", 2 * self.fem.size(), "u"), int(zero_u)), "DDH.local_solution_listed")
+
     def local_solution(self, d0, d1, lam, f, u, zero_u=True):
         N.check_capi(lib.cuddh_ddh_local_solution(self._h, d0, d1, _ptr(lam, self.trace_dtype, self.size(), "lambda"), _ptr(f, "f64", 2 * self.fem.size(), "f"),
                                                    _ptr(u, "f64", 2 * self.fem.size(), "u"), int(zero_u)), "DDH.local_solution")

@@ -51,6 +51,8 @@ namespace cuddh
                        Real *update) const;
             /// traces only, for the n subdomains listed in d_domains (DEVICE), one launch (cuddh_hip_ddh_apply_list_*)
             void solve_listed(const int *d_domains, int n, const double *x, const Real *lambda, Real *update) const;
+            /// the general form for listed subdomains (solution output y as in solve())
+            void solve_listed(const int *d_domains, int n, const double *x, double *y, bool zero_y, const Real *lambda, Real *update) const;
 
             // host copies of the constructor's tables (tests compare them with the oracle)
             const host_device_ivec &table_B() const { return _Bf; }
@@ -74,6 +76,8 @@ namespace cuddh
             int elems_per_side() const { return nel1d; }
 
         private:
+            void solve_impl(const int *d_list, int d0, int d1, const double *x, double *y, bool zero_y, const Real *lambda, Real *update) const;
+
             /// device-side part of the set-up (geometric factors, kernel plan); deferred to first use so
             /// that the host tables can be built and inspected without a GPU
             void ensure_plan() const;

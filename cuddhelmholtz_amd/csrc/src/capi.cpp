@@ -746,6 +746,17 @@ extern "C"
                 h->f32->internals().solve_listed(d_domains, n, f, static_cast<const float *>(lambda), static_cast<float *>(update));
         });
     }
+    int cuddh_ddh_local_solution_listed(void *d, const int *d_domains, int n, const void *lambda, const double *f, double *u, int zero_u)
+    {
+        return guarded([&]
+        {
+            auto *h = static_cast<DdhHandle *>(d);
+            if (h->is64())
+                h->f64->internals().solve_listed(d_domains, n, f, u, zero_u != 0, static_cast<const double *>(lambda), nullptr);
+            else
+                h->f32->internals().solve_listed(d_domains, n, f, u, zero_u != 0, static_cast<const float *>(lambda), nullptr);
+        });
+    }
     int cuddh_ddh_local_solution(void *d, int d0, int d1, const void *lambda, const double *f, double *u, int zero_u)
     {
         return guarded([&]

@@ -417,14 +417,30 @@ namespace cuddh
         template <typename Real>
         void DDHCore<Real>::solve(int d0, int d1, const double *x, double *y, bool zero_y, const Real *lambda, Real *update) const
         {
+            solve_impl(nullptr, d0, d1, x, y, zero_y, lambda, update);
+        }
+
+        template <typename Real>
+        void DDHCore<Real>::solve_listed(const int *d_domains, int n, const double *x, double *y, bool zero_y, const Real *lambda,
+                                         Real *update) const
+        {
+            solve_impl(d_domains, 0, n, x, y, zero_y, lambda, update);
+        }
+
+        template <typename Real>
+        void DDHCore<Real>::solve_impl(const int *d_list, int d0, int d1, const double *x, double *y, bool zero_y, const Real *lambda,
+                                       Real *update) const
+        {
             ensure_plan();
             auto run = [&](const double *xx, double *yy, bool zy)
             {
                 int err;
                 if constexpr (std::is_same_v<Real, float>)
-                    err = cuddh_hip_ddh_apply_f32(plan, d0, d1, xx, yy, zy ? 1 : 0, lambda, update, stream());
+                    err = d_list ? cuddh_hip_ddh_apply_list_f32(plan, d_list, d1, xx, yy, zy ? 1 : 0, lambda, update, stream())
+                                 : cuddh_hip_ddh_apply_f32(plan, d0, d1, xx, yy, zy ? 1 : 0, lambda, update, stream());
                 else
-                    err = cuddh_hip_ddh_apply_f64(plan, d0, d1, xx, yy, zy ? 1 : 0, lambda, update, stream());
+                    err = d_list ? cuddh_hip_ddh_apply_list_f64(plan, d_list, d1, xx, yy, zy ? 1 : 0, lambda, update, stream())
+                                 : cuddh_hip_ddh_apply_f64(plan, d0, d1, xx, yy, zy ? 1 : 0, lambda, update, stream());
                 check_hip(err, "DDH local solves");
             };
             if (!y)
@@ -466,13 +482,7 @@ namespace cuddh
         template <typename Real>
         void DDHCore<Real>::solve_listed(const int *d_domains, int n, const double *x, const Real *lambda, Real *update) const
         {
-            ensure_plan();
-            int err;
-            if constexpr (std::is_same_v<Real, float>)
-                err = cuddh_hip_ddh_apply_list_f32(plan, d_domains, n, x, nullptr, 0, lambda, update, stream());
-            else
-                err = cuddh_hip_ddh_apply_list_f64(plan, d_domains, n, x, nullptr, 0, lambda, update, stream());
-            check_hip(err, "DDH local solves (listed subdomains)");
+            solve_impl(d_domains, 0, n, x, nullptr, false, lambda, update);
         }
 
         template class DDHCore<float>;

@@ -483,22 +483,10 @@ namespace cuddh
 
                 t0 = clk::now();
                 double *d_u = u.device_write();
-                // (once per solve: run by run when the rank's subdomains are a rectangle of the block grid)
-                {
-                    bool first = true;
-                    const std::vector<int> &dm = R.plan.domains;
-                    for (std::size_t i = 0; i < dm.size();)
-                    {
-                        std::size_t j = i + 1;
-                        while (j < dm.size() && dm[j] == dm[j - 1] + 1)
-                            ++j;
-                        R.F->local_solution(dm[i], dm[j - 1] + 1, d_lam, d_f, d_u, first);
-                        first = false;
-                        i = j;
-                    }
-                    if (first) // a rank without subdomains still contributes zeros to the sum below
-                        detail::check_hip(cuddh_hip_memset_zero(d_u, sizeof(double) * 2 * ndof, R.st), "solution zero fill");
-                }
+                if (R.all_ids.size() > 0) // a rectangle of the block grid: one listed launch
+                    R.F->internals().solve_listed(R.all_ids.device_read(), R.all_ids.size(), d_f, d_u, true, d_lam, nullptr);
+                else
+                    R.F->local_solution(R.plan.dom_begin, R.plan.dom_end, d_lam, d_f, d_u, true);
                 R.all_reduce(d_u, 2 * static_cast<size_t>(ndof), ncclDouble); // partition-of-unity sums cross the pieces
                 R.sync();
                 t_post[rank] = since(t0);

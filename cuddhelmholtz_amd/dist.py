@@ -371,9 +371,18 @@ class NeighbourShardedDDH:
 
     def postprocess(self, lam, f, u) -> None:
         """reference DDH::postprocess (source/DDH.cpp:669-695); u is summed over the ranks (once per solve)"""
+        import torch
+
         u.zero_()
-        for a, b in _runs(self.ex.domains):  # (once per solve: range by range when the rank's subdomains are a rectangle)
-            self.engine.local_solution(a, b, lam, f, u, False)
+        runs = _runs(self.ex.domains)
+        listed = getattr(self.engine, "local_solution_listed", None)
+        if len(runs) > 1 and listed is not None:  # a rectangle of the block grid: one listed launch
+            if "all" not in self._lists:
+                self._lists["all"] = torch.tensor(self.ex.domains, dtype=torch.int32, device=self.device)
+            listed(self._lists["all"], lam, f, u, False)
+        else:
+            for a, b in runs:
+                self.engine.local_solution(a, b, lam, f, u, False)
         self.reduce(u)
 
     def full(self, v):

@@ -145,6 +145,7 @@ int cuddh_ddh_action(void *ddh, const void *x, void *y);
 int cuddh_ddh_local_traces(void *ddh, int d0, int d1, const double *f, const void *lambda, void *update);
 /* the same for n listed subdomains (d_domains: DEVICE ints, distinct, in range) in one launch */
 int cuddh_ddh_local_traces_listed(void *ddh, const int *d_domains, int n, const double *f, const void *lambda, void *update);
+int cuddh_ddh_local_solution_listed(void *ddh, const int *d_domains, int n, const void *lambda, const double *f, double *u, int zero_u);
 int cuddh_ddh_local_solution(void *ddh, int d0, int d1, const void *lambda, const double *f, double *u, int zero_u);
 /* HOST copies of the constructor's tables: name in {"B","gI","sI"} (int) or
  * {"D","G","m","gmi","a","H","filter","cs","sn"} (float / double by f64).  count_only != 0: just return the length. */
