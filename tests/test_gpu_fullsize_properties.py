@@ -297,3 +297,64 @@ def test_ddh_properties_at_full_size(cuda, big):
     assert torch.equal(torch.stack(outs).sum(0), upd_whole)
     owned = torch.cat([r.owned_idx for r in grid])
     assert owned.numel() == torch.unique(owned).numel()
+
+
+@pytest.mark.parametrize("coef", ["one", "disk"])
+def test_config3_ddh_properties_at_full_size(cuda, coef):
+    """BASELINE config 3 at its own size and frequency: 512 x 512 quads, omega = 16 pi (32 elements per wavelength, nt = 5120),
+    n_basis 4, 16,384 reference-size subdomains, with a = 1 and with the example's disk coefficient (examples/DDH.cpp:74-83,
+    lumped-projected as in :122-123).  Size-independent properties of the benchmarked fp32 kernel: bitwise repeatability,
+    exact homogeneity under scaling by 2, ranges == whole, the listed one-launch form == whole, finiteness; and one Arnoldi
+    cycle of the reference's flow (rhs -> gmres(20), one cycle) returning a finite, reduced residual.  (Entry-point parity
+    against the oracle in this regime: tests/test_baseline_regime.py.)"""
+    import torch
+
+    import cuddhelmholtz_amd as cd
+
+    nx, nb, omega = 512, 4, 16 * math.pi
+    mesh = cd.Mesh2D.uniform_rect(nx, -1.0, 1.0, nx, -1.0, 1.0)
+    fem = cd.H1Space(mesh, cd.Basis(nb))
+    n = fem.size()
+    assert n == 2362369  # SURVEY 8d
+    a = torch.ones(n, dtype=torch.float64, device=cuda)
+    if coef == "disk":
+        cd.linear_functional(fem, cd.ALPHA_DISK, a)
+        cd.DiagInvMassMatrix(fem).action(a, a)
+    F = cd.DDH(omega, a.cpu().numpy(), fem, nx, nx)
+    info = F.info()
+    assert (info["n_domains"], info["nt"], info["kernel"]) == (16384, 5120, 5)
+    assert F.size() // 4 == 2 * 128 * 127 * 13
+    g = torch.Generator(device="cpu").manual_seed(3)
+    lam = (2 * torch.rand(F.size(), generator=g) - 1).to(cuda)
+    y1, y2, y3 = (torch.zeros_like(lam) for _ in range(3))
+    F.action(lam, y1)
+    F.action(lam, y2)
+    assert torch.equal(y1, y2)
+    F.action(2.0 * lam, y3)
+    assert torch.equal(y3, 2.0 * y1)
+    assert bool(torch.isfinite(y1).all())
+    whole, parts, listed = (torch.zeros_like(lam) for _ in range(3))
+    F.local_traces(0, 16384, None, lam, whole)
+    for d0, d1 in ((0, 4097), (4097, 9000), (9000, 16384)):
+        F.local_traces(d0, d1, None, lam, parts)
+    assert torch.equal(whole, parts)
+    perm = torch.randperm(16384, generator=g).to(torch.int32).to(cuda)
+    F.local_traces_listed(perm[:5001], None, lam, listed)
+    F.local_traces_listed(perm[5001:], None, lam, listed)
+    assert torch.equal(whole, listed)
+    growth = float(whole.double().norm() / lam.double().norm())
+    print(f"config 3 (512^2, omega=16pi, a={coef}): |T lambda|/|lambda| = {growth:.3e} for random traces")
+    if coef == "one":
+        assert growth < 1.5  # non-expansive local solves
+    else:
+        assert growth > 1e3  # the reference's time stepping is unstable here (tests/test_baseline_regime.py)
+    f = torch.zeros(2 * n, dtype=torch.float64, device=cuda)
+    cd.linear_functional(fem, cd.GAUSSIANS, f[:n], param=omega)
+    b = torch.zeros_like(lam)
+    F.rhs(f, b)
+    assert bool(torch.isfinite(b).all()) and float(b.norm()) > 0
+    x = torch.zeros_like(b)
+    out = cd.gmres(F.size(), x, F, b, 20, 2, 1e-4)  # one cycle (the reference's loop runs maxit - 1 cycles)
+    assert out.num_matvec == 22 and all(math.isfinite(r) for r in out.res_norm)
+    print(f"  one GMRES(20) cycle: relative residual {out.res_norm[-1] / out.res_norm[0]:.3e}")
+    assert out.res_norm[-1] < out.res_norm[0]
