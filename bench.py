@@ -25,6 +25,15 @@ reading reference DDH supports), fp32 local solves (the reference's precision), 
            assembly is cross-checked at start-up against the replicated-vector form (one all-reduce
            of the 27 MB trace vector per step, --exchange allreduce), which is also the fallback.
 
+  coefficient: the headline runs the reference example's own two-valued disk coefficient (examples/DDH.cpp:74-83, a = 0.2
+           inside r < 0.25).  In BASELINE's regime (32 elements per wavelength, nt = 5120) the reference's time stepping is
+           UNSTABLE with it (|T| ~ 1e7: tests/test_baseline_regime.py), so fp32 results carry no meaningful digits there; the time
+           per step does not depend on the values.  `stable_coefficient` therefore times the same K steps with a = 1, where the
+           local solves are non-expansive and fp32 agrees with the fp64 oracle to 1e-6 (same test file).
+  N > 1 fields: `exchange` (neighbour | allreduce), `fell_back`, `exchange_bytes`, `rank_grid`, `action_ms` (per-rank local
+           solves + exchange, min / max over ranks), `roofline_sharded` (the partitioned global operator apply, fraction of
+           N x 8 TB/s).  An explicit `--exchange neighbour` that falls back ends non-zero.
+
 Extra objects on the same JSON line:
   roofline     = the global operator apply (fused complex Helmholtz apply on the same mesh, in the
                  GENERAL-geometry layout), the HBM-bound kernel of the path: algorithmic bytes /
@@ -104,19 +113,26 @@ def main() -> None:
     ap.add_argument("--nx", type=int, default=1024, help="elements per side (default: the metric's 1024)")
     ap.add_argument("--nb", type=int, default=4)
     ap.add_argument("--kernel", type=int, default=0, help="DDH kernel: 0 auto, 1 workgroup, 2 wavefront, 3 wavefront with DPP-folded FMAs")
-    ap.add_argument("--exchange", choices=("neighbour", "allreduce"), default="neighbour",
-                    help="N > 1: partitioned trace vectors with neighbour send/recv (default) or replicated vectors with one all-reduce")
+    ap.add_argument("--exchange", choices=("auto", "neighbour", "allreduce"), default="auto",
+                    help="N > 1: partitioned trace vectors with neighbour send/recv, or replicated vectors with one all-reduce.  auto "
+                         "(default) = neighbour, falling back to allreduce if the start-up cross-check fails (reported as "
+                         "fell_back); an explicit `neighbour` that fails its check ends the run non-zero instead")
+    ap.add_argument("--coefficient", choices=("disk", "one"), default="disk",
+                    help="disk: the example's two-valued coefficient (examples/DDH.cpp:74-83); one: a = 1")
+    ap.add_argument("--no-stable-coefficient", action="store_true", help="skip the second timed loop with a = 1")
     ap.add_argument("--rehearse-gloo", action="store_true",
                     help="rehearsal of the N > 1 host logic on ONE GPU: all ranks share cuda:0, process group on gloo with host-staged "
                          "payloads (RCCL needs one GPU per rank).  Not a measurement.")
-    ap.add_argument("--sharded-apply", action="store_true",
-                    help="N > 1: also time the partitioned global Helmholtz apply (element partition + halo exchanges, "
-                         "cuddhelmholtz_amd.dist.ShardedHelmholtz) and report its aggregate rate as `roofline_sharded`")
-    ap.add_argument("--rank-grid", default="", metavar="GXxGY",
-                    help="N > 1: ranks own rectangles of the subdomain grid (GX x GY = N, SURVEY 8e) instead of strips of block rows")
+    ap.add_argument("--sharded-apply", action=argparse.BooleanOptionalAction, default=True,
+                    help="N > 1 (default on): also time the partitioned global Helmholtz apply (element partition + halo exchanges) "
+                         "and report its aggregate rate as `roofline_sharded`, fraction of N x 8 TB/s")
+    ap.add_argument("--rank-grid", default="auto", metavar="GXxGY|strips|auto",
+                    help="N > 1: ranks own rectangles of the subdomain grid (GX x GY = N).  auto (default): SURVEY 8e's grids "
+                         "2x1, 2x2, 2x4 for N = 2, 4, 8, strips of block rows otherwise; strips: contiguous subdomain ranges")
     ap.add_argument("--overlap", action="store_true",
                     help="N > 1: split schedule (boundary subdomains first, on a second stream with issue priority, exchange behind "
                          "them, interior meanwhile); default is exchange-after-solve")
+    ap.add_argument("--inject-neighbour-failure", action="store_true", help=argparse.SUPPRESS)  # tests: the start-up cross-check "fails"
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-gmres-call", action="store_true", help="skip the real gmres() call timed beside the step loop")
@@ -170,117 +186,100 @@ def main() -> None:
     gmres_m = 20
 
     # ---------------------------------------------------------------- problem set-up (untimed)
+    from cuddhelmholtz_amd import _native as N
+    from cuddhelmholtz_amd.dist import NeighbourShardedDDH, ShardedDDH, rank_grid_map
+
+    lib = N.lib
     t_setup = time.time()
     mesh = cd.Mesh2D.uniform_rect(nx, -1.0, 1.0, nx, -1.0, 1.0)
     basis = cd.Basis(nb)
     fem = cd.H1Space(mesh, basis)
     ndof = fem.size()
     f = torch.zeros(2 * ndof, dtype=torch.float64, device=dev)
-    a = torch.zeros(ndof, dtype=torch.float64, device=dev)
     cd.linear_functional(fem, cd.GAUSSIANS, f[:ndof], param=omega)  # examples/DDH.cpp:120
-    cd.linear_functional(fem, cd.ALPHA_DISK, a)                      # examples/DDH.cpp:122-123
-    mi = cd.DiagInvMassMatrix(fem)
-    mi.action(a, a)
-    h_a = a.cpu().numpy()
-    F = cd.DDH(omega, h_a, fem, nx, nx, precision="f32", kernel=args.kernel)
+
+    def coefficient(name):
+        a = torch.ones(ndof, dtype=torch.float64, device=dev)
+        if name == "disk":
+            cd.linear_functional(fem, cd.ALPHA_DISK, a)              # examples/DDH.cpp:122-123
+            cd.DiagInvMassMatrix(fem).action(a, a)
+        return a.cpu().numpy()
+
+    F = cd.DDH(omega, coefficient(args.coefficient), fem, nx, nx, precision="f32", kernel=args.kernel)
     info = F.info()
     n = F.size()
     nd = info["n_domains"]
-    from cuddhelmholtz_amd.dist import NeighbourShardedDDH, ShardedDDH
+    ndx = nx // info["nel1d"]
+    ndy = nd // ndx
 
-    # N > 1: each rank solves a contiguous range of subdomains.  Default: trace vectors partitioned by slot ownership,
-    # traces for other ranks sent to the (<= 2) neighbouring ranks (grouped RCCL send/recv), inner products all-reduced.
-    # Fallback (--exchange allreduce, or if the start-up cross-check below fails): replicated vectors, one all-reduce.
-    sh_all = ShardedDDH(F, nd, rank, world, always_reduce=dist.is_initialized(), host_staging=staged)
-    b = torch.zeros(n, dtype=torch.float32, device=dev)
-    torch.cuda.synchronize()
-    t_constructors = time.time() - t_setup  # mesh, spaces, coefficient projection, DDH constructor + kernel plan
-    sh_all.rhs(f, b)
-    exchange, exchange_note = ("allreduce" if world > 1 else "none"), ""
-    sh = sh_all
-    if world > 1 and args.exchange == "neighbour":
-        ok, sh_nb, b_nb = 0.0, None, None
+    # N > 1: which subdomains a rank owns.  SURVEY 8e: rectangles of the subdomain grid (2x1, 2x2, 2x4 for 2, 4, 8 ranks: at
+    # most four face neighbours, shorter messages than strips); strips of block rows (contiguous ranges) otherwise.
+    grid = None
+    if world > 1 and args.rank_grid != "strips":
+        if args.rank_grid == "auto":
+            grid = {2: (2, 1), 4: (2, 2), 8: (2, 4)}.get(world)
+        else:
+            gx, gy = (int(v) for v in args.rank_grid.lower().split("x"))
+            if gx * gy != world:
+                raise SystemExit(f"bench.py: --rank-grid {args.rank_grid} does not have {world} ranks")
+            grid = (gx, gy)
+        if grid and (grid[0] > ndx or grid[1] > ndy):
+            grid = None
+    dom_rank = rank_grid_map(ndx, ndy, *grid) if grid else None
+    grid_name = f"{grid[0]}x{grid[1]}" if grid else ("strips" if world > 1 else "1x1")
+
+    def shard(Fx, check: bool):
+        """N > 1: the sharded operator on DDH object Fx.  Default: trace vectors partitioned by slot ownership, traces for other
+        ranks sent to the neighbouring ranks (grouped RCCL send/recv), inner products all-reduced.  Fallback (--exchange
+        allreduce, or --exchange auto when the start-up cross-check fails): replicated vectors, one all-reduce per action.
+        Returns (operator, rhs vector, exchange, note)."""
+        sh_all = ShardedDDH(Fx, nd, rank, world, always_reduce=dist.is_initialized(), host_staging=staged)
+        bx = torch.zeros(n, dtype=torch.float32, device=dev)
+        sh_all.rhs(f, bx)
+        if world == 1:
+            return sh_all, bx, "none", ""
+        if args.exchange == "allreduce":
+            return sh_all, bx, "allreduce", ""
+        ok, sh_nb, b_nb, note = 0.0, None, None, ""
         try:
-            dom_rank = None
-            if args.rank_grid:
-                from cuddhelmholtz_amd.dist import rank_grid_map
-
-                gx, gy = (int(v) for v in args.rank_grid.lower().split("x"))
-                if gx * gy != world:
-                    raise SystemExit(f"bench.py: --rank-grid {args.rank_grid} does not have {world} ranks")
-                ndx = nx // info["nel1d"]
-                dom_rank = rank_grid_map(ndx, nd // ndx, gx, gy)
-            sh_nb = NeighbourShardedDDH(F, nd, rank, world, device=dev, host_staging=staged, overlap=args.overlap,
+            sh_nb = NeighbourShardedDDH(Fx, nd, rank, world, device=dev, host_staging=staged, overlap=args.overlap,
                                         set_stream=cd.use_torch_stream, dom_rank=dom_rank)
-            b_nb = torch.zeros_like(b)
+            b_nb = torch.zeros_like(bx)
             sh_nb.rhs(f, b_nb)
             # traces are copied, not summed: the assembled vector must be bitwise the all-reduce result
-            ok = 1.0 if torch.equal(sh_nb.full(b_nb), b) else 0.0
+            ok = 1.0 if (not check or torch.equal(sh_nb.full(b_nb), bx)) else 0.0
+            if args.inject_neighbour_failure and rank == world - 1:
+                ok = 0.0
             if ok == 0.0:
-                exchange_note = "neighbour exchange disagreed with the all-reduce assembly at start-up; fell back"
+                note = "neighbour exchange disagreed with the all-reduce assembly at start-up; fell back"
         except Exception as e:  # noqa: BLE001 - keep the run alive on the proven path and say so
-            exchange_note = f"neighbour exchange unavailable ({type(e).__name__}: {e}); fell back"
+            note = f"neighbour exchange unavailable ({type(e).__name__}: {e}); fell back"
         flag = torch.tensor([ok], device=dev)
         allred(flag, dist.ReduceOp.MIN)  # every rank takes the same branch
         if float(flag.item()) == 1.0:
-            sh, b, exchange = sh_nb, b_nb, "neighbour"
-        elif not exchange_note:
-            exchange_note = "neighbour exchange failed its start-up check on another rank; fell back"
+            return sh_nb, b_nb, "neighbour", ""
+        return sh_all, bx, "allreduce", note or "neighbour exchange failed its start-up check on another rank; fell back"
+
+    torch.cuda.synchronize()
+    t_constructors = time.time() - t_setup  # mesh, spaces, coefficient projection, DDH constructor + kernel plan
+    sh, b, exchange, exchange_note = shard(F, check=True)
+    fell_back = bool(exchange_note)
     partitioned = exchange == "neighbour"
     torch.cuda.synchronize()
     t_setup = time.time() - t_setup
+    if fell_back and args.exchange == "neighbour":
+        # asked for explicitly: a silent 27 MB all-reduce per action would not be the path the caller wanted measured
+        if rank == 0:
+            print(f"bench.py: --exchange neighbour was requested but {exchange_note}", file=sys.stderr)
+        if dist.is_initialized():
+            dist.barrier()
+            dist.destroy_process_group()
+        raise SystemExit(3)
 
     # ---------------------------------------------------------------- Arnoldi steps
-    from cuddhelmholtz_amd import _native as N
-
-    lib = N.lib
-    V = torch.zeros((gmres_m + 1, n), dtype=torch.float32, device=dev)
-    hcol = torch.zeros(gmres_m + 2, dtype=torch.float32, device=dev)
-    ws = torch.zeros(lib.cuddh_hip_reduce_ws_bytes() // 4, dtype=torch.float32, device=dev)
-    upd = torch.zeros(n, dtype=torch.float32, device=dev)
+    ws_half = lib.cuddh_hip_reduce_ws_bytes() // 2  # the two partial-sum buffers of the fused MGS stages (src/krylov.cpp)
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
-
-    bb = torch.dot(b, b).reshape(1)
-    if partitioned:
-        allred(bb)
-    V[0].copy_(b / torch.sqrt(bb))
-
-    ws_half = lib.cuddh_hip_reduce_ws_bytes() // 2  # the two partial-sum buffers of the fused MGS stages (src/krylov.cpp)
-    h_host = torch.zeros(gmres_m + 2, dtype=torch.float32).pin_memory()
-
-    def arnoldi_step(k: int) -> None:
-        """One Arnoldi step exactly as the product's gmres() issues it (csrc/src/krylov.cpp, reference source/gmres.cpp:160-179)."""
-        vk, vk1 = V[k], V[k + 1]
-        if world == 1:
-            F.action(vk, vk1)  # DDH::action: local solves, then v_{k+1} = v_k - T v_k
-        else:
-            # local solves of this rank's subdomains, then the trace exchange / reassembly
-            sh.traces(None, vk, upd)
-            N.check(lib.cuddh_hip_copy_f32(n, p(vk), p(vk1), st))
-            N.check(lib.cuddh_hip_axpby_f32(n, -1.0, p(upd), 1.0, p(vk1), st))
-        if partitioned:
-            # vectors partitioned over the ranks: every coefficient is the all-reduced sum of the local dots (MGS parity mode)
-            for j in range(k + 1):
-                N.check(lib.cuddh_hip_dot_f32(n, p(vk1), p(V[j]), p(hcol[j:]), p(ws), st))
-                allred(hcol[j:j + 1])
-                N.check(lib.cuddh_hip_axpby_dev_f32(n, -1.0, p(hcol[j:]), p(V[j]), 1.0, p(vk1), st))
-            N.check(lib.cuddh_hip_dot_f32(n, p(vk1), p(vk1), p(hcol[k + 1:]), p(ws), st))
-            allred(hcol[k + 1:k + 2])
-            hcol[k + 1:k + 2].sqrt_()
-            N.check(lib.cuddh_hip_scal_inv_dev_f32(n, p(hcol[k + 1:]), p(vk1), st))
-        else:
-            # fused stages: stage j applies the projection on v_{j-1} and leaves the partial sums of <w, v_j> for stage j+1
-            pa, pb = ws.data_ptr(), ws.data_ptr() + ws_half
-            N.check(lib.cuddh_hip_mgs_stage_f32(n, p(vk1), None, p(V[0]), C.c_void_p(pa), C.c_void_p(pa), p(hcol), st))
-            for j in range(k + 1):
-                vnext = p(V[j + 1]) if j + 1 < k + 1 else None
-                N.check(lib.cuddh_hip_mgs_stage_f32(n, p(vk1), p(V[j]), vnext, C.c_void_p(pa), C.c_void_p(pb), p(hcol[j:]), st))
-                pa, pb = pb, pa
-            N.check(lib.cuddh_hip_mgs_finish_f32(n, p(vk1), C.c_void_p(pa), p(hcol[k + 1:]), st))
-        h_host[: k + 2].copy_(hcol[: k + 2])  # the Hessenberg column reaches the host once per step (Givens on the host)
-        if k + 1 == gmres_m:  # restart: continue from the last basis vector
-            V[0].copy_(vk1)
 
     def barrier():
         torch.cuda.synchronize()
@@ -288,25 +287,77 @@ def main() -> None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    step_id = 0
-    for _ in range(args.warmup):
-        arnoldi_step(step_id % gmres_m)
-        step_id += 1
-    barrier()
-    t0 = time.perf_counter()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    ev0.record()
-    for _ in range(args.steps):
-        arnoldi_step(step_id % gmres_m)
-        step_id += 1
-    ev1.record()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        allred(tmax, dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-    finite = bool(torch.isfinite(V).all().item())
+    class Stepper:
+        """K Arnoldi steps of GMRES(20) on (Fx, shx) from the normalised right-hand side, exactly as the product's gmres() issues
+        them (csrc/src/krylov.cpp, reference source/gmres.cpp:160-179)."""
+
+        def __init__(self, Fx, shx, bx, part):
+            self.F, self.sh, self.part = Fx, shx, part
+            self.V = torch.zeros((gmres_m + 1, n), dtype=torch.float32, device=dev)
+            self.hcol = torch.zeros(gmres_m + 2, dtype=torch.float32, device=dev)
+            self.ws = torch.zeros(lib.cuddh_hip_reduce_ws_bytes() // 4, dtype=torch.float32, device=dev)
+            self.upd = torch.zeros(n, dtype=torch.float32, device=dev)
+            self.h_host = torch.zeros(gmres_m + 2, dtype=torch.float32).pin_memory()
+            bb = torch.dot(bx, bx).reshape(1)
+            if part:
+                allred(bb)
+            self.V[0].copy_(bx / torch.sqrt(bb))
+            self.step_id = 0
+
+        def step(self) -> None:
+            k = self.step_id % gmres_m
+            self.step_id += 1
+            V, hcol, ws, upd = self.V, self.hcol, self.ws, self.upd
+            vk, vk1 = V[k], V[k + 1]
+            if world == 1:
+                self.F.action(vk, vk1)  # DDH::action: local solves, then v_{k+1} = v_k - T v_k
+            else:
+                # local solves of this rank's subdomains, then the trace exchange / reassembly
+                self.sh.traces(None, vk, upd)
+                N.check(lib.cuddh_hip_copy_f32(n, p(vk), p(vk1), st))
+                N.check(lib.cuddh_hip_axpby_f32(n, -1.0, p(upd), 1.0, p(vk1), st))
+            if self.part:
+                # vectors partitioned over the ranks: every coefficient is the all-reduced sum of the local dots (MGS parity mode)
+                for j in range(k + 1):
+                    N.check(lib.cuddh_hip_dot_f32(n, p(vk1), p(V[j]), p(hcol[j:]), p(ws), st))
+                    allred(hcol[j:j + 1])
+                    N.check(lib.cuddh_hip_axpby_dev_f32(n, -1.0, p(hcol[j:]), p(V[j]), 1.0, p(vk1), st))
+                N.check(lib.cuddh_hip_dot_f32(n, p(vk1), p(vk1), p(hcol[k + 1:]), p(ws), st))
+                allred(hcol[k + 1:k + 2])
+                hcol[k + 1:k + 2].sqrt_()
+                N.check(lib.cuddh_hip_scal_inv_dev_f32(n, p(hcol[k + 1:]), p(vk1), st))
+            else:
+                # fused stages: stage j applies the projection on v_{j-1} and leaves the partial sums of <w, v_j> for stage j+1
+                pa, pb = ws.data_ptr(), ws.data_ptr() + ws_half
+                N.check(lib.cuddh_hip_mgs_stage_f32(n, p(vk1), None, p(V[0]), C.c_void_p(pa), C.c_void_p(pa), p(hcol), st))
+                for j in range(k + 1):
+                    vnext = p(V[j + 1]) if j + 1 < k + 1 else None
+                    N.check(lib.cuddh_hip_mgs_stage_f32(n, p(vk1), p(V[j]), vnext, C.c_void_p(pa), C.c_void_p(pb), p(hcol[j:]), st))
+                    pa, pb = pb, pa
+                N.check(lib.cuddh_hip_mgs_finish_f32(n, p(vk1), C.c_void_p(pa), p(hcol[k + 1:]), st))
+            self.h_host[: k + 2].copy_(hcol[: k + 2])  # the Hessenberg column reaches the host once per step (Givens on the host)
+            if k + 1 == gmres_m:  # restart: continue from the last basis vector
+                V[0].copy_(vk1)
+
+        def timed(self, steps, warmup):
+            """W untimed + exactly K timed steps between barrier + synchronize on both sides; MAX over ranks"""
+            for _ in range(warmup):
+                self.step()
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                self.step()
+            barrier()
+            elapsed = time.perf_counter() - t0
+            if world > 1:
+                tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+                allred(tmax, dist.ReduceOp.MAX)
+                elapsed = float(tmax.item())
+            return elapsed, bool(torch.isfinite(self.V).all().item())
+
+    stepper = Stepper(F, sh, b, partitioned)
+    elapsed, finite = stepper.timed(args.steps, args.warmup)
+    upd = stepper.upd
 
     value = 2.0 * ndof * args.steps / elapsed
     ms_per_step = 1e3 * elapsed / args.steps
@@ -318,6 +369,10 @@ def main() -> None:
     executed = {3: 244 * 128.0, 5: 8 * 2 * 16 * 16 * 4 + 80 * 128.0}.get(info["kernel"])
     exec_tf = None if executed is None else executed * 5 * info["nt"] * nd * args.steps / elapsed / 1e12 / world
 
+    coef_text = {"disk": "coefficient = the example's two-valued disk (a = 0.2 for r < 0.25, examples/DDH.cpp:74-83, lumped-projected as in "
+                         ":122-123; the reference's local solves are UNSTABLE with it at 32 elements per wavelength, see `stable_coefficient`)",
+                 "one": "coefficient a = 1"}[args.coefficient]
+    send_idx = getattr(sh, "send_idx", {})
     result = {
         "metric": "DDH-GMRES DoF*iter/s",
         "value": value,
@@ -334,22 +389,26 @@ def main() -> None:
         "config": {
             "workload": f"DDH-GMRES(20) Arnoldi steps, omega={omega / math.pi:g}pi, {nx}x{nx} quads uniform_rect, n_basis={nb} "
                         f"(reference tests' Basis(p) reading of p={nb}), {nd} reference-size subdomains "
-                        f"({info['nel1d']}x{info['nel1d']} elements each), nt={info['nt']} RK2 steps x 5 WaveHoltz iterations per action",
+                        f"({info['nel1d']}x{info['nel1d']} elements each), nt={info['nt']} RK2 steps x 5 WaveHoltz iterations per action, "
+                        + coef_text,
+            "coefficient": args.coefficient,
             "g_ndof": ndof,
             "n_traces": n,
             "ddh_kernel": {1: "workgroup-per-subdomain", 2: "wavefront-per-subdomain", 3: "wavefront-per-subdomain, DPP-folded FMAs", 4: "wavefront-per-subdomain, DPP-folded FMAs + 4x4x1 MFMA", 5: "wavefront-per-subdomain, dense 16x16 element matrix on MFMA (v_mfma_f32_16x16x4_f32)", 6: "wavefront per two subdomains (n_basis 8), DPP-folded FMAs", 7: "wavefront per two subdomains (n_basis 8), separable sweep"}.get(info["kernel"], str(info["kernel"])),
             "sharding": {"none": "single GPU",
                          "allreduce": f"{world} contiguous subdomain ranges, replicated trace vectors, one RCCL all-reduce of the trace vector per step",
-                         "neighbour": f"{world} " + ("rectangles of the subdomain grid" if args.rank_grid else "contiguous subdomain ranges")
+                         "neighbour": f"{world} " + (f"rectangles of the subdomain grid ({grid_name})" if grid else "contiguous subdomain ranges")
                                       + ", trace vectors partitioned by slot ownership, grouped RCCL "
-                                      f"send/recv of {sum(i.numel() for i in getattr(sh, 'send_idx', {}).values()) * 4 / 1024:.0f} KiB to "
-                                      f"{len(getattr(sh, 'send_idx', {}))} neighbour rank(s) per step (rank 0), all-reduce of each inner product"}[exchange]
+                                      f"send/recv of {sum(i.numel() for i in send_idx.values()) * 4 / 1024:.0f} KiB to "
+                                      f"{len(send_idx)} neighbour rank(s) per step (rank 0), all-reduce of each inner product"}[exchange]
                         + (", split schedule (boundary subdomains first with issue priority, exchange behind them)" if (args.overlap and exchange == "neighbour") else "")
-                        + (f", rank grid {args.rank_grid}" if (args.rank_grid and exchange == "neighbour") else "")
+                        + (f", rank grid {grid_name}" if (grid and exchange == "neighbour") else "")
                         + (f" [{exchange_note}]" if exchange_note else ""),
             "setup_seconds": round(t_constructors, 3),  # Mesh2D + H1Space + load vector / coefficient + DDH constructor + plan
             "rhs_and_exchange_check_seconds": round(t_setup - t_constructors, 3),  # DDH::rhs (one pass of local solves) [+ N > 1 start-up check]
             "finite": finite,
+            "replicated_per_rank": "every rank builds all subdomains' tables and keeps global-length Krylov vectors (zero outside the "
+                                   "slots it owns); neither is sharded" if world > 1 else None,
         },
         "ddh_kernel": {
             "bound": "fp32-valu/lds (not HBM-bound; SURVEY 8d)",
@@ -359,11 +418,64 @@ def main() -> None:
             "frac": ddh_tf / FP32_VECTOR_PEAK_TF,
             "flops_per_action": flops_step,
             "note": "achieved counts the algorithm's FLOPs (sum-factorised sweeps); executed_tflops counts what the kernel issues "
-                    "(kernel 5 applies a dense 16x16 element matrix on v_mfma_f32_16x16x4_f32, which runs at the vector rate on gfx950)",
+                    "(kernel 5 applies a dense 16x16 element matrix on v_mfma_f32_16x16x4_f32, which runs on the SIMD's fp32 vector lanes "
+                    "on gfx950: same peak, no co-execution with VALU -- profiles/r03/mfma_valu_coexec.txt)",
             "executed_tflops": exec_tf,
             "executed_frac": None if exec_tf is None else exec_tf / FP32_VECTOR_PEAK_TF,
         },
     }
+
+    # ---------------------------------------------------------------- N > 1: what the exchange is and what a rank's action costs
+    if world > 1:
+        my_bytes = float(sum(i.numel() for i in send_idx.values()) * 4) if partitioned else float(n * 4)
+        lam_probe = stepper.V[0]
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        reps = 3
+        barrier()
+        t_act, t_solve = 0.0, 0.0
+        for _ in range(reps):
+            e0.record()
+            if partitioned:
+                sh._solve("all", None, lam_probe, upd)  # local solves only (no exchange)
+            else:
+                F.local_traces(sh.d0, sh.d1, None, lam_probe, upd)
+            e1.record()
+            sh.traces(None, lam_probe, upd)             # local solves + exchange / reassembly, as in a step
+            e2.record()
+            torch.cuda.synchronize()
+            t_solve += e0.elapsed_time(e1) / reps
+            t_act += e1.elapsed_time(e2) / reps
+        stats = torch.tensor([t_act, -t_act, t_solve, -t_solve, my_bytes, -my_bytes], dtype=torch.float64, device=dev)
+        allred(stats, dist.ReduceOp.MAX)
+        tot = torch.tensor([my_bytes, t_act], dtype=torch.float64, device=dev)
+        allred(tot)
+        mx_act, mn_act, mx_solve, mn_solve, mx_b, mn_b = (float(v) for v in stats.tolist())
+        result["exchange"] = exchange
+        result["fell_back"] = fell_back
+        result["rank_grid"] = grid_name if partitioned else "strips"
+        result["exchange_bytes"] = {"per_action_rank_max": mx_b, "per_action_rank_min": -mn_b, "per_action_all_ranks": float(tot[0].item()),
+                                    "what": "packed trace values (fp32) a rank sends to its neighbours per DDH::action" if partitioned
+                                            else "the replicated trace vector all-reduced per DDH::action (bytes per rank)"}
+        result["action_ms"] = {"max": mx_act, "min": -mn_act, "mean": float(tot[1].item()) / world,
+                               "local_solves_only_max": mx_solve, "local_solves_only_min": -mn_solve,
+                               "what": "per-rank HIP-event time of one sharded DDH::action (local solves of the rank's subdomains + trace "
+                                       "exchange), outside the timed loop; min / max over ranks"}
+    else:
+        result["exchange"], result["fell_back"], result["rank_grid"] = "none", False, "1x1"
+
+    # ---------------------------------------------------------------- the same K steps with a = 1 (stable local solves)
+    if args.coefficient != "one" and not args.no_stable_coefficient:
+        F1 = cd.DDH(omega, coefficient("one"), fem, nx, nx, precision="f32", kernel=args.kernel)
+        sh1, b1, ex1, note1 = shard(F1, check=False)
+        st1 = Stepper(F1, sh1, b1, ex1 == "neighbour")
+        el1, fin1 = st1.timed(args.steps, args.warmup)
+        result["stable_coefficient"] = {
+            "coefficient": "a = 1 (local solves non-expansive at 32 elements per wavelength; fp32 kernel vs fp64 oracle 6e-6 on a window of "
+                           "this configuration, tests/test_baseline_regime.py)",
+            "value": 2.0 * ndof * args.steps / el1, "unit": "DoF*iter/s", "ms_per_step": 1e3 * el1 / args.steps, "steps": args.steps,
+            "warmup": args.warmup, "finite": fin1, "exchange": ex1, "ratio_to_value": (2.0 * ndof * args.steps / el1) / value,
+        }
+        del st1, sh1, F1
 
     # ---------------------------------------------------------------- one real gmres() call (SURVEY 8d's definition of the metric)
     if not args.no_gmres_call:
@@ -397,12 +509,18 @@ def main() -> None:
     if rank == 0 and not args.no_roofline:
         result["roofline"] = helmholtz_roofline(cd, torch, dev, fem, mesh, omega, ndof)
 
-    # ---------------------------------------------------------------- optional: the partitioned global apply over the N ranks
+    # ---------------------------------------------------------------- the partitioned global apply over the N ranks
     if world > 1 and args.sharded_apply:
         try:
             result_sh = sharded_apply_rate(cd, torch, dist, dev, fem, mesh, omega, ndof, rank, world, staged, allred)
+            err = 0.0
         except Exception as e:  # noqa: BLE001
             result_sh = {"error": f"{type(e).__name__}: {e}"}
+            err = 1.0
+        flag = torch.tensor([err], device=dev)
+        allred(flag, dist.ReduceOp.MAX)
+        if float(flag.item()) and "error" not in result_sh:
+            result_sh = {"error": "the partitioned apply failed on another rank"}
         if rank == 0:
             result["roofline_sharded"] = result_sh
 
@@ -451,9 +569,12 @@ def sharded_apply_rate(cd, torch, dist, dev, fem, mesh, omega, ndof, rank, world
     n_elem, nb = mesh.n_elem(), fem.basis.n
     nqS, nqM, nqF = nb + 1, 2 + 3 * nb // 2, 2 + 3 * nb // 2
     b_alg = n_elem * (3 * nqS * nqS * 8 + nqM * nqM * 8 + nb * nb * 4) + ndof * 32 + fs.n_faces() * (nqF * 8 + nb * 4)
-    return {"label": "fused Helmholtz apply partitioned over the ranks (element partition + two halo exchanges per apply)",
-            "achieved": b_alg / t / 1e9, "unit": "GB/s", "seconds_per_apply": t, "algorithmic_bytes": b_alg,
-            "local_dofs_rank0": A.n_loc, "halo_dofs_rank0": int(A.part.halo.size)}
+    peak = world * HBM_PEAK_GBS
+    return {"label": "fused Helmholtz apply partitioned over the ranks (element partition + two halo exchanges per apply), general-geometry layout",
+            "bound": "hbm", "achieved": b_alg / t / 1e9, "peak": peak, "unit": "GB/s", "frac": b_alg / t / 1e9 / peak,
+            "seconds_per_apply": t, "algorithmic_bytes": b_alg, "n_gpus": world,
+            "local_dofs_rank0": A.n_loc, "halo_dofs_rank0": int(A.part.halo.size),
+            "halo_exchange_bytes_rank0": int(A.part.halo.size) * 2 * 8 * 2}
 
 
 def helmholtz_roofline(cd, torch, dev, fem, mesh, omega, ndof):

@@ -89,6 +89,7 @@ _sig("cuddh_hip_memset_zero", ci, vp, cs, vp)
 _sig("cuddh_hip_stream_sync", ci, vp)
 _sig("cuddh_hip_device_sync", ci)
 _sig("cuddh_hip_device_count", ci)
+_sig("cuddh_hip_current_device", ci)
 _sig("cuddh_hip_error_string", cp, ci)
 _sig("cuddh_hip_reduce_ws_bytes", cs)
 _sig("cuddh_hip_axpby_f64", ci, ci, cd, vp, cd, vp, vp)
@@ -158,6 +159,7 @@ _sig("cuddh_hip_ddh_apply_f64", ci, vp, ci, ci, vp, vp, ci, vp, vp, vp)
 # ---- handle layer (cuddh_capi.h)
 _sig("cuddh_last_error", cp)
 _sig("cuddh_set_stream", None, vp)
+_sig("cuddh_get_stream", vp)
 _sig("cuddh_quadrature", ci, ci, ci, vp, vp)
 _sig("cuddh_basis_create", vp, ci)
 _sig("cuddh_basis_destroy", None, vp)

@@ -54,10 +54,46 @@ def _needs_rebuild(obj: Path, src: Path, headers_mtime: float) -> bool:
     return m < src.stat().st_mtime or m < headers_mtime
 
 
+# what the last build()/build_native()/build_examples() calls of this process did: written to build/BUILD_INFO.json so that a
+# reader of the tree can see whether objects were compiled or reused
+BUILD_LOG: dict = {"compiled": [], "reused": [], "linked": [], "drivers_built": [], "drivers_reused": []}
+
+
+def write_build_info() -> Path:
+    import json
+    import time
+
+    def run(*cmd):
+        try:
+            return subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT).stdout.strip()
+        except OSError:
+            return ""
+
+    hipcc_version = next((ln for ln in run(hipcc(), "--version").splitlines() if "HIP version" in ln or "clang version" in ln), "")
+    info = {
+        "written_at": time.strftime("%Y-%m-%dT%H:%M:%S%z"),
+        "arch": ARCH,
+        "hipcc": hipcc_version,
+        "git_head": run("git", "rev-parse", "HEAD"),
+        "git_dirty": bool(run("git", "status", "--porcelain", "--", "cuddhelmholtz_amd", "include", "oracle")),
+        "build_mode": "compiled" if BUILD_LOG["compiled"] or BUILD_LOG["drivers_built"] else "reused (every object newer than its sources and headers)",
+        **{k: sorted(set(v)) for k, v in BUILD_LOG.items()},
+        "library": str(LIB_PATH.relative_to(ROOT)),
+        "library_bytes": LIB_PATH.stat().st_size if LIB_PATH.exists() else 0,
+        "reference_tree_present": REFERENCE_EXAMPLES.exists(),
+    }
+    out = ROOT / "build" / "BUILD_INFO.json"
+    out.parent.mkdir(parents=True, exist_ok=True)
+    out.write_text(json.dumps(info, indent=1) + "\n")
+    return out
+
+
 def _compile(src: Path, as_hip: bool, headers_mtime: float, verbose: bool) -> Path:
     obj = OBJ_DIR / (src.name + ".o")
     if not _needs_rebuild(obj, src, headers_mtime):
+        BUILD_LOG["reused"].append(src.name)
         return obj
+    BUILD_LOG["compiled"].append(src.name)
     cmd = [hipcc(), *COMMON, *[f"-I{p}" for p in INCLUDES]]
     if as_hip:
         cmd += HIP_FLAGS
@@ -91,6 +127,8 @@ def build_native(verbose: bool = False, jobs: int = 6) -> Path:
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+        BUILD_LOG["linked"].append(LIB_PATH.name)
+    write_build_info()
     return LIB_PATH
 
 
@@ -116,12 +154,19 @@ def build_examples(verbose: bool = False) -> list[Path]:
     for src, name in jobs:
         out = EXAMPLES_DIR / name
         if isinstance(src, list):
-            if out.exists() and out.stat().st_mtime > max(max(f.stat().st_mtime for f in src), LIB_PATH.stat().st_mtime):
+            env_hdr = CSRC / "examples" / "reference_tests_env.hpp"
+            if out.exists() and out.stat().st_mtime > max(max(f.stat().st_mtime for f in src), LIB_PATH.stat().st_mtime, env_hdr.stat().st_mtime):
                 outs.append(out)
+                BUILD_LOG["drivers_reused"].append(name)
                 continue
+            BUILD_LOG["drivers_built"].append(name)
             cmd = [hipcc(), "-O2", "-std=c++17", "-x", "hip", f"--offload-arch={ARCH}", "-munsafe-fp-atomics",
                    *[f"-I{p}" for p in INCLUDES], f"-I{src[0].parent}",
-                   '-DUNSTRUCTURED_SQUARE_MESH_DIR="/root/repo/tests/golden/unstructured_square"', *map(str, src), "-o", str(out),
+                   # the reference reads `std::string dir = UNSTRUCTURED_SQUARE_MESH_DIR;` (tests/load_unstructured_square.cpp:13): the
+                   # macro is an expression here, resolved at run time from the binary's own location (or CUDDH_MESH_DIR), so the
+                   # driver works from any checkout path
+                   "-include", str(CSRC / "examples" / "reference_tests_env.hpp"), "-DUNSTRUCTURED_SQUARE_MESH_DIR=cuddh_reference_mesh_dir()",
+                   *map(str, src), "-o", str(out),
                    f"-L{LIB_DIR}", "-lcuddh_amd", "-Wl,-rpath,$ORIGIN/../../cuddhelmholtz_amd/lib"]
             r = subprocess.run(cmd, capture_output=True, text=True)
             if r.returncode != 0:
@@ -130,7 +175,9 @@ def build_examples(verbose: bool = False) -> list[Path]:
             continue
         if out.exists() and out.stat().st_mtime > max(src.stat().st_mtime, LIB_PATH.stat().st_mtime):
             outs.append(out)
+            BUILD_LOG["drivers_reused"].append(name)
             continue
+        BUILD_LOG["drivers_built"].append(name)
         cmd = [hipcc(), "-O2", "-std=c++17", "-x", "hip", f"--offload-arch={ARCH}", "-munsafe-fp-atomics",
                *[f"-I{p}" for p in INCLUDES], f"-I{CSRC / 'examples'}", f"-I{REFERENCE_EXAMPLES}", str(src), "-o", str(out),
                f"-L{LIB_DIR}", "-lcuddh_amd", "-Wl,-rpath,$ORIGIN/../../cuddhelmholtz_amd/lib"]
@@ -140,6 +187,7 @@ def build_examples(verbose: bool = False) -> list[Path]:
         if r.returncode != 0:
             raise RuntimeError(f"building {name} failed:\n{r.stderr}")
         outs.append(out)
+    write_build_info()
     return outs
 
 

@@ -80,5 +80,16 @@ extern "C"
         return n;
     }
 
+    int cuddh_hip_current_device(void)
+    {
+        int d = 0;
+        if (hipGetDevice(&d) != hipSuccess)
+        {
+            (void)hipGetLastError();
+            return -1;
+        }
+        return d;
+    }
+
     const char *cuddh_hip_error_string(int err) { return hipGetErrorString(static_cast<hipError_t>(err)); }
 }

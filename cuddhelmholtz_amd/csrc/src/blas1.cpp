@@ -9,7 +9,8 @@ namespace cuddh
 {
     namespace
     {
-        // persistent reduction workspace + one device scalar, created on first use
+        // persistent reduction workspace + one device scalar, created on first use -- one per (host thread, device): the launch
+        // stream is per thread (runtime.cpp), so two threads reducing on their own streams or devices must not share partial sums
         struct ReduceScratch
         {
             void *ws = nullptr;
@@ -26,7 +27,12 @@ namespace cuddh
 
         ReduceScratch &scratch()
         {
-            static ReduceScratch s; // intentionally never freed: outlives every stream
+            constexpr int max_devices = 64;
+            thread_local ReduceScratch per_device[max_devices]; // intentionally never freed: outlives every stream
+            int dev = cuddh_hip_current_device();
+            if (dev < 0 || dev >= max_devices)
+                dev = 0;
+            ReduceScratch &s = per_device[dev];
             s.ensure();
             return s;
         }

@@ -173,6 +173,7 @@ extern "C"
     const char *cuddh_last_error(void) { return g_error.c_str(); }
 
     void cuddh_set_stream(void *s) { set_stream(static_cast<hipStream_t>(s)); }
+    void *cuddh_get_stream(void) { return stream(); }
 
     // ------------------------------------------------------------ quadrature / basis
     int cuddh_quadrature(int n, int type, double *h_x, double *h_w)

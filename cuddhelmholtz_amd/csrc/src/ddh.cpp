@@ -452,6 +452,10 @@ namespace cuddh
             // (source/DDH.cpp:298-307), in whatever order the blocks finish.  Here the subdomains write into their own entries
             // (identity numbering) and a second kernel sums the copies of each global dof in increasing subdomain order:
             // postprocess is bitwise reproducible and equals a serial loop over the subdomains.
+            // (footprint of this fixed-order assembly: two arrays of 2 * mx_dof * n_domains doubles, 0.54 GB at 1024^2 with n_basis 4,
+            // kept for the lifetime of the object once a solution output was asked for; index arithmetic is 32-bit)
+            if (2LL * mx_dof * n_domains > 2147483647LL)
+                cuddh_error("DDH error: solution assembly needs 2 * mx_dof * n_domains < 2^31 (about 8192^2 elements at n_basis 4).");
             ensure_assembly();
             const int N = mx_dof * n_domains;
             const int *d_loc = _gI_local.device_read();

@@ -226,7 +226,20 @@ namespace cuddh
                 out.res_norm.push_back(static_cast<double>(r_nrm));
                 const double elapsed = std::chrono::duration<double>(clock::now() - t0).count();
                 out.time.push_back(elapsed);
-                if (elapsed > max_seconds)
+                bool out_of_time = elapsed > max_seconds;
+                if (red)
+                {
+                    // each rank reads its own clock: the decision to stop must be the same on all of them, or one rank leaves the
+                    // sequence of collectives while the others enter the next one -- reduce the flag like every other scalar
+                    const scalar flag = out_of_time ? one : zero;
+                    scalar total = zero;
+                    detail::check_hip(cuddh_hip_copy_h2d_on(dcol, &flag, sizeof(scalar), stream()), "gmres stop flag");
+                    red->fn(red->user, dcol, 1, is_f64);
+                    detail::check_hip(cuddh_hip_stream_sync(stream()), "gmres sync");
+                    detail::check_hip(cuddh_hip_copy_d2h_on(&total, dcol, sizeof(scalar), stream()), "gmres stop flag");
+                    out_of_time = total > zero;
+                }
+                if (out_of_time)
                     break;
 
                 if (verbose == 1)

@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <exception>
 #include <condition_variable>
@@ -126,6 +127,7 @@ namespace cuddh
         {
             decltype(&ncclCommInitAll) CommInitAll = nullptr;
             decltype(&ncclCommDestroy) CommDestroy = nullptr;
+            decltype(&ncclCommAbort) CommAbort = nullptr;
             decltype(&ncclGroupStart) GroupStart = nullptr;
             decltype(&ncclGroupEnd) GroupEnd = nullptr;
             decltype(&ncclSend) Send = nullptr;
@@ -167,6 +169,7 @@ namespace cuddh
                 };
                 bind(a.CommInitAll, "ncclCommInitAll");
                 bind(a.CommDestroy, "ncclCommDestroy");
+                bind(a.CommAbort, "ncclCommAbort");
                 bind(a.GroupStart, "ncclGroupStart");
                 bind(a.GroupEnd, "ncclGroupEnd");
                 bind(a.Send, "ncclSend");
@@ -193,9 +196,13 @@ namespace cuddh
         struct Loopback
         {
             explicit Loopback(int world) : n(world), box(static_cast<std::size_t>(world) * world, nullptr), vals(world) {}
+            /// all ranks meet here -- or leave with an exception as soon as any rank has failed (abort()), so that one rank's error
+            /// never leaves the others waiting for it
             void barrier()
             {
                 std::unique_lock<std::mutex> lk(m);
+                if (failed)
+                    throw std::runtime_error("multi-GPU solve: another rank failed");
                 const long gen = generation;
                 if (++arrived == n)
                 {
@@ -204,8 +211,21 @@ namespace cuddh
                     cv.notify_all();
                 }
                 else
-                    cv.wait(lk, [&] { return generation != gen; });
+                {
+                    cv.wait(lk, [&] { return generation != gen || failed; });
+                    if (generation == gen)
+                        throw std::runtime_error("multi-GPU solve: another rank failed");
+                }
             }
+            void abort()
+            {
+                {
+                    std::lock_guard<std::mutex> lk(m);
+                    failed = true;
+                }
+                cv.notify_all();
+            }
+            bool failed = false;
             int n;
             std::vector<const float *> box; // box[from * n + to]: device pointer of the message from -> to
             std::vector<std::vector<double>> vals;
@@ -232,6 +252,28 @@ namespace cuddh
             TraceExchangePlan plan;
             std::map<int, HostDeviceArray<int>> send_slots, recv_slots;
             std::map<int, HostDeviceArray<float>> sbuf, rbuf;
+
+            Rank() = default;
+            Rank(const Rank &) = delete;
+            ~Rank() // also on the exception path: operators first (they launch on st), then the streams and events
+            {
+                F.reset();
+                fem.reset();
+                if (st_side)
+                {
+                    (void)hipStreamSynchronize(st_side);
+                    (void)hipStreamDestroy(st_side);
+                }
+                if (ev_main)
+                    (void)hipEventDestroy(ev_main);
+                if (ev_side)
+                    (void)hipEventDestroy(ev_side);
+                if (st)
+                {
+                    (void)hipStreamSynchronize(st);
+                    (void)hipStreamDestroy(st);
+                }
+            }
 
             void sync() const { detail::check_hip(cuddh_hip_stream_sync(st), "stream sync"); }
 
@@ -383,6 +425,19 @@ namespace cuddh
         const bool use_rccl = !loopback && (world > 1 || transport == 1);
         Loopback loop_state(world);
 
+        // rank 0 runs on the caller's thread: whatever happens below, the caller gets its launch stream and current device back
+        struct CallerState
+        {
+            hipStream_t st = stream();
+            int dev = 0;
+            CallerState() { (void)hipGetDevice(&dev); }
+            ~CallerState()
+            {
+                set_stream(st);
+                (void)hipSetDevice(dev);
+            }
+        } caller_state;
+
         std::vector<ncclComm_t> comms(world, nullptr);
         if (use_rccl)
         {
@@ -399,6 +454,26 @@ namespace cuddh
         std::vector<solver_out> outs(world);
         std::vector<std::exception_ptr> errors(world);
         std::mutex host_out; // h_u is written by rank 0 only; the mutex guards nothing else
+        // One rank's failure must end the call on every rank: the loopback barrier is released with an error, RCCL communicators are
+        // aborted (ncclCommAbort makes pending and later collectives on them return), so no thread stays blocked in a collective.
+        std::atomic<bool> any_failed{false};
+        std::mutex abort_once;
+        auto abort_all = [&]()
+        {
+            std::lock_guard<std::mutex> lock(abort_once);
+            if (any_failed.exchange(true))
+                return;
+            loop_state.abort();
+            for (auto &c : comms)
+                if (c)
+                {
+                    (void)Rccl::get().CommAbort(c);
+                    c = nullptr;
+                }
+        };
+        // test hook (tests/test_gpu_native_drivers.py): CUDDH_MULTIGPU_FAIL_RANK=r makes rank r throw after its right-hand side
+        const char *fail_env = std::getenv("CUDDH_MULTIGPU_FAIL_RANK");
+        const int fail_rank = fail_env ? std::atoi(fail_env) : -1;
 
         auto body = [&](int rank)
         {
@@ -472,6 +547,8 @@ namespace cuddh
                 R.traces(d_f, nullptr, d_b); // DDH::rhs on the partitioned vectors
                 R.sync();
                 t_rhs[rank] = since(t0);
+                if (rank == fail_rank)
+                    throw std::runtime_error("multi-GPU solve: injected failure (CUDDH_MULTIGPU_FAIL_RANK)");
 
                 ShardOperator A(R);
                 const ScalarReduce red{reduce_hook, &R};
@@ -495,22 +572,13 @@ namespace cuddh
                     std::lock_guard<std::mutex> lock(host_out);
                     std::memcpy(h_u, u.host_read(), sizeof(double) * 2 * ndof);
                 }
-                R.F.reset();
-                R.fem.reset();
-                set_stream(nullptr);
-                if (R.st_side)
-                {
-                    (void)hipStreamSynchronize(R.st_side);
-                    (void)hipEventDestroy(R.ev_main);
-                    (void)hipEventDestroy(R.ev_side);
-                    (void)hipStreamDestroy(R.st_side);
-                }
-                (void)hipStreamDestroy(R.st);
             }
             catch (...)
             {
                 errors[rank] = std::current_exception();
+                abort_all();
             }
+            set_stream(nullptr); // R (streams, events, operators) is gone; this thread launches on no dead stream
         };
 
         std::vector<std::thread> threads;
@@ -522,10 +590,34 @@ namespace cuddh
         for (auto &c : comms)
             if (c)
                 (void)Rccl::get().CommDestroy(c);
-        (void)hipSetDevice(0);
+        // report the first rank's own error, not the "another rank failed" of the ranks it released
+        std::exception_ptr first;
         for (const auto &e : errors)
-            if (e)
+        {
+            if (!e)
+                continue;
+            bool secondary = false;
+            try
+            {
                 std::rethrow_exception(e);
+            }
+            catch (const std::exception &ex)
+            {
+                secondary = std::strstr(ex.what(), "another rank failed") != nullptr;
+            }
+            catch (...)
+            {
+            }
+            if (!secondary)
+            {
+                first = e;
+                break;
+            }
+            if (!first)
+                first = e;
+        }
+        if (first)
+            std::rethrow_exception(first);
 
         res.gmres = outs[0];
         res.t_setup = *std::max_element(t_setup.begin(), t_setup.end());

@@ -20,6 +20,8 @@ extern "C" {
 const char *cuddh_last_error(void);
 /* stream used by every subsequent launch of the library (NULL = null stream) */
 void cuddh_set_stream(void *stream);
+/* the calling thread's current launch stream (NULL = the null stream) */
+void *cuddh_get_stream(void);
 
 /* ---- quadrature / basis (reference include/QuadratureRule.hpp, include/Basis.hpp); HOST arrays */
 /* type 0 = Gauss-Legendre, 1 = Gauss-Lobatto */

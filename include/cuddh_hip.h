@@ -42,6 +42,8 @@ int cuddh_hip_stream_sync(void *stream);
 int cuddh_hip_device_sync(void);
 /* number of visible devices; 0 if there is no GPU (never fails) */
 int cuddh_hip_device_count(void);
+/* the calling thread's current device (hipGetDevice), -1 if there is none; the BLAS-1 wrappers key their reduction scratch by it */
+int cuddh_hip_current_device(void);
 const char *cuddh_hip_error_string(int err);
 
 /* ------------------------------------------------------------------ BLAS-1

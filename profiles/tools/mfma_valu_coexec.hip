@@ -80,6 +80,63 @@ __global__ void __launch_bounds__(512) xdl_kernel(float *out, int units)
     out[blockIdx.x * 512 + threadIdx.x] = c0.x + c1.y + c2.z + c3.w + a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
 }
 
+#define VGROUP2                                                                                                            \
+    "v_fmac_f32 %0, %9, %8\n\tv_fmac_f32 %1, %9, %8\n\tv_fmac_f32 %2, %9, %8\n\tv_fmac_f32 %3, %9, %8\n\t"                  \
+    "v_fmac_f32 %4, %9, %8\n\tv_fmac_f32 %5, %9, %8\n\tv_fmac_f32 %6, %9, %8\n\tv_fmac_f32 %7, %9, %8\n\t"
+// controls and fine-grained in-wave interleaving.  MODE 10: waves 0-3 and waves 4-7 run two COPIES of the v_fmac_f32 loop (different
+// code addresses, same pipe: isolates instruction-fetch effects of two programs per SIMD); 11: every wave, per unit 8 x (1 bf16 MFMA +
+// 8 v_fmac_f32) -- the full VALU count with the matrix work spread through it; 12: per unit 4 x (1 fp32 MFMA + 16 v_fmac_f32)
+template <int MODE>
+__global__ void __launch_bounds__(512) fine_kernel(float *out, int units)
+{
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    f4 c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0;
+    float a0 = threadIdx.x, a1 = 1, a2 = 2, a3 = 3, a4 = 4, a5 = 5, a6 = 6, a7 = 7;
+    const float a = 1.0f + 1e-7f * threadIdx.x, c = 1e-9f, b = 1e-6f;
+    bf8 ba, bb;
+    for (int i = 0; i < 8; ++i)
+    {
+        ba[i] = (__bf16)(1.0f + 0.01f * (threadIdx.x & 7));
+        bb[i] = (__bf16)(1e-3f * i);
+    }
+    if (MODE == 10)
+    {
+        if (wave >= 4)
+            for (int u = 0; u < units; ++u)
+                asm volatile(REP8(VGROUP2) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(a), "v"(c));
+        else
+            for (int u = 0; u < units; ++u)
+                asm volatile(REP8(VGROUP) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(a), "v"(c));
+    }
+    else if (MODE == 11)
+    {
+        for (int u = 0; u < units; ++u)
+        {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+            {
+                f4 &cc = (j & 3) == 0 ? c0 : (j & 3) == 1 ? c1 : (j & 3) == 2 ? c2 : c3;
+                cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ba, bb, cc, 0, 0, 0);
+                asm volatile(VGROUP : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(a), "v"(c));
+            }
+        }
+    }
+    else
+    {
+        for (int u = 0; u < units; ++u)
+        {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+            {
+                f4 &cc = j == 0 ? c0 : j == 1 ? c1 : j == 2 ? c2 : c3;
+                cc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, cc, 0, 0, 0);
+                asm volatile(VGROUP VGROUP : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(a), "v"(c));
+            }
+        }
+    }
+    out[blockIdx.x * 512 + threadIdx.x] = c0.x + c1.y + c2.z + c3.w + a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
+}
+
 // MODE 0: every wave MFMA; 1: every wave VALU; 2: waves >= 4 VALU, others MFMA; 3: odd waves VALU; 4: both kinds interleaved in every
 // wave (half the units of each, so that a wave alone needs T); 5: like 2 but the VALU waves run DPP-modified fmacs (half rate)
 template <int MODE>
@@ -176,5 +233,9 @@ int main()
     std::printf("bf16: all-MFMA %.3f ms (%.1f cycles per instruction and SIMD at 2.4 GHz); split by wave: %.3f ms (max(T_m, T_v) = %.3f if co-executing, sum = %.3f if exclusive);\n"
                 "      in-wave half each: %.3f ms (exclusive: %.3f); in-wave full VALU + half MFMA: %.3f ms (VALU alone: %.3f)\n",
                 xm, xm * 1e-3 * 2.4e9 / (2.0 * units * 8), xx, 0.5f * (xm > v ? xm : v), 0.5f * (xm + v), xs, 0.5f * (xm + v), xf, v);
+    std::printf("-- controls and fine-grained in-wave interleaving (full v_fmac_f32 count in every wave: %.3f ms if the matrix work hides) --\n", v);
+    run("control: waves 0-3 / 4-7 run two copies of the v_fmac_f32 loop", fine_kernel<10>, units);
+    run("every wave: 8 x (1 bf16 MFMA + 8 v_fmac_f32) per unit", fine_kernel<11>, units);
+    run("every wave: 4 x (1 fp32 MFMA + 16 v_fmac_f32) per unit", fine_kernel<12>, units);
     return 0;
 }

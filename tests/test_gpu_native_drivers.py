@@ -234,8 +234,11 @@ def test_multi_gpu_host_loopback_ranks(cuda, world, split, grid):
     F.rhs(f, b)
     out = cd.gmres(F.size(), lam, F, b, 20, 100, 1e-4)
     F.postprocess(lam, f, u)
+    from cuddhelmholtz_amd import _native as N
+
+    stream_before = N.lib.cuddh_get_stream()
     u_multi, info = ddh_solve_multi_gpu(nx, nb, omega, h_a, h_f, world=world, m=20, maxit=100, tol=1e-4, force_rccl=2, split_schedule=split, rank_grid=grid)
-    cd.use_torch_stream()
+    assert N.lib.cuddh_get_stream() == stream_before  # the call gives the caller's launch stream back (rank 0 ran on this thread)
     assert info["world"] == world and not info["used_rccl"] and info["success"] == int(out.success) == 1
     assert info["bytes_sent_per_action_rank0"] > 0
     assert abs(info["num_matvec"] - out.num_matvec) <= 2
@@ -273,10 +276,51 @@ def test_multi_gpu_host_one_rank(cuda, force_rccl):
     out = cd.gmres(F.size(), lam, F, b, 20, 100, 1e-4)
     F.postprocess(lam, f, u)
     u_multi, info = ddh_solve_multi_gpu(nx, nb, omega, h_a, h_f, world=1, m=20, maxit=100, tol=1e-4, force_rccl=force_rccl)
-    cd.use_torch_stream()  # the host above ran on its own stream and left this thread on the null stream
     assert info["world"] == 1 and bool(info["used_rccl"]) == force_rccl and info["success"] == int(out.success) == 1
     assert abs(info["num_matvec"] - out.num_matvec) <= 2
     err = float(np.linalg.norm(u_multi - u.cpu().numpy()) / np.linalg.norm(u.cpu().numpy()))
     print(f"multi-GPU host, one rank, rccl={force_rccl}: {info['num_matvec']} matvecs (plain {out.num_matvec}), u vs plain solve {err:.2e}, "
           f"t_gmres {info['t_gmres']:.2f} s")
     assert err < 1e-3
+
+
+@pytest.mark.parametrize("world,fail_rank,split", [(2, 1, False), (3, 0, False), (4, 2, True)])
+def test_multi_gpu_host_rank_failure_ends_the_call(cuda, monkeypatch, world, fail_rank, split):
+    """One rank throwing (here: injected after its right-hand side through the test hook CUDDH_MULTIGPU_FAIL_RANK) must end the
+    call on every rank with that rank's error -- not leave the others blocked in the next barrier / collective.
+    Afterwards the caller's stream is intact and a second, healthy call still works."""
+    import threading
+
+    import torch
+
+    import cuddhelmholtz_amd as cd
+    from cuddhelmholtz_amd import _native as N
+    from cuddhelmholtz_amd.dist import ddh_solve_multi_gpu
+
+    nx, nb = 16, 4
+    omega = 2 * math.pi * nx / 10
+    fem = cd.H1Space(cd.Mesh2D.uniform_rect(nx, -1.0, 1.0, nx, -1.0, 1.0), cd.Basis(nb))
+    n = fem.size()
+    f = torch.zeros(2 * n, dtype=torch.float64, device=cuda)
+    cd.linear_functional(fem, cd.GAUSSIANS, f[:n], param=omega)
+    h_a, h_f = np.ones(n), f.cpu().numpy()
+    stream_before = N.lib.cuddh_get_stream()
+    monkeypatch.setenv("CUDDH_MULTIGPU_FAIL_RANK", str(fail_rank))
+    result = {}
+
+    def call():
+        try:
+            ddh_solve_multi_gpu(nx, nb, omega, h_a, h_f, world=world, m=20, maxit=50, tol=1e-4, force_rccl=2, split_schedule=split)
+            result["error"] = None
+        except Exception as e:  # noqa: BLE001
+            result["error"] = str(e)
+
+    t = threading.Thread(target=call, daemon=True)
+    t.start()
+    t.join(120)
+    assert not t.is_alive(), "ddh_solve_multi_gpu did not return after one rank failed"
+    assert result["error"] and "injected failure" in result["error"], result
+    monkeypatch.delenv("CUDDH_MULTIGPU_FAIL_RANK")
+    assert N.lib.cuddh_get_stream() == stream_before
+    u, info = ddh_solve_multi_gpu(nx, nb, omega, h_a, h_f, world=world, m=20, maxit=50, tol=1e-4, force_rccl=2, split_schedule=split)
+    assert info["success"] == 1 and np.isfinite(u).all()

@@ -62,19 +62,25 @@ def test_two_processes_neighbour_exchange(cuda, tmp_path, precision, overlap, gr
             assert len(boundary) == 8 and len(interior) == 8
 
 
-@pytest.mark.parametrize("split,grid", [(False, ""), (True, ""), (True, "2x1")])
+def run_bench_two_ranks(extra):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), str(ROOT / "bench.py"), "--gpus", "2", "--rehearse-gloo", "--nx", "64", "--steps", "3",
+           "--warmup", "1", "--no-roofline"] + extra
+    return subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
+
+
+@pytest.mark.parametrize("split,grid", [(False, "strips"), (True, "strips"), (True, ""), (False, "1x2")])
 def test_bench_two_rank_rehearsal(cuda, split, grid):
     """bench.py's N > 1 code path (partition, neighbour exchange chosen after its start-up cross-check against the
     all-reduce assembly, reduced inner products, max-over-ranks timing, one JSON line from rank 0) with two ranks
     sharing the GPU over gloo; with and without the split schedule (boundary subdomains as one listed launch with issue
     priority on a second stream -- the start-up cross-check then compares THAT assembly bitwise with the all-reduce one).
-    The printed rate is not a measurement."""
+    grid "" = bench.py's default for the rank count (2x1 for two ranks).  The N > 1 line is self-sufficient:
+    exchange kind, fell_back, bytes exchanged, per-rank action time, and the partitioned global apply as `roofline_sharded`
+    with its fraction of N x 8 TB/s.  The printed rates are not measurements."""
     import json
 
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(free_port()), str(ROOT / "bench.py"), "--gpus", "2", "--rehearse-gloo", "--nx", "64", "--steps", "3",
-           "--warmup", "1", "--no-roofline"] + (["--overlap"] if split else []) + (["--rank-grid", grid] if grid else [])
-    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    r = run_bench_two_ranks((["--overlap"] if split else []) + (["--rank-grid", grid] if grid else []))
     assert r.returncode == 0, r.stdout + r.stderr
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
@@ -82,8 +88,42 @@ def test_bench_two_rank_rehearsal(cuda, split, grid):
     assert out["n_gpus"] == 2 and out["steps"] == 3 and out["scaling"] == "strong" and out["config"]["finite"]
     assert "partitioned by slot ownership" in out["config"]["sharding"] and "fell back" not in out["config"]["sharding"]
     assert ("split schedule" in out["config"]["sharding"]) == split
-    assert ("rank grid" in out["config"]["sharding"]) == bool(grid)
+    assert out["rank_grid"] == (grid or "2x1")
+    assert ("rank grid" in out["config"]["sharding"]) == (grid != "strips")
     assert "cpu_baseline" not in out  # N = 1 only
+    assert out["exchange"] == "neighbour" and out["fell_back"] is False
+    xb, am = out["exchange_bytes"], out["action_ms"]
+    # 64 x 64 elements = 16 x 16 subdomains: the cut between two ranks crosses 16 subdomain edges of 13 trace dofs, minus the
+    # slots lost to the cross-point quirk at each of the 15 interior cross points on the cut (2 per cross point on a horizontal cut,
+    # 1 on a vertical one: the pair order follows the global edge numbering), lambda and mu halves, 4 bytes
+    lost = 1 if out["rank_grid"] == "2x1" else 2
+    assert xb["per_action_rank_max"] == xb["per_action_rank_min"] == 2 * (16 * 13 - lost * 15) * 4
+    assert xb["per_action_all_ranks"] == 2 * xb["per_action_rank_max"]
+    assert 0 < am["min"] <= am["mean"] <= am["max"] and 0 < am["local_solves_only_min"] <= am["local_solves_only_max"]
+    rs = out["roofline_sharded"]
+    assert "error" not in rs, rs
+    assert rs["peak"] == 2 * 8000.0 and rs["n_gpus"] == 2 and abs(rs["frac"] - rs["achieved"] / rs["peak"]) < 1e-12 and rs["achieved"] > 0
+    sc = out["stable_coefficient"]
+    assert sc["finite"] and sc["value"] > 0 and sc["exchange"] == "neighbour"
+    assert "disk" in out["config"]["workload"] and out["config"]["coefficient"] == "disk"
+
+
+def test_bench_neighbour_fallback_is_loud(cuda):
+    """When the neighbour exchange fails its start-up cross-check (injected on one rank): with the default `--exchange auto` the
+    run continues on the all-reduce assembly and SAYS so at top level (`fell_back`, `exchange`); with an explicit
+    `--exchange neighbour` it ends non-zero and prints no result line."""
+    import json
+
+    r = run_bench_two_ranks(["--inject-neighbour-failure", "--no-sharded-apply", "--no-stable-coefficient"])
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["fell_back"] is True and out["exchange"] == "allreduce" and "fell back" in out["config"]["sharding"]
+    assert out["exchange_bytes"]["per_action_rank_max"] == out["config"]["n_traces"] * 4
+    assert "roofline_sharded" not in out and "stable_coefficient" not in out
+    r = run_bench_two_ranks(["--inject-neighbour-failure", "--exchange", "neighbour", "--no-sharded-apply", "--no-stable-coefficient"])
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert "--exchange neighbour was requested" in r.stderr
 
 
 def test_partitioned_helmholtz_replay_in_one_process(cuda):
