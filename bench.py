@@ -635,7 +635,21 @@ def helmholtz_roofline(cd, torch, dev, fem, mesh, omega, ndof):
     prev = os.environ.get("CUDDH_PLAN_AFFINE")
     os.environ["CUDDH_PLAN_AFFINE"] = "0"
     A = cd.HelmholtzOperator(omega, a2, ax, fem, fs)
-    t = timed(A)
+    t_ref = timed(A)
+    # the same plan on vectors in ITS OWN ordering (pairs (u, v), a patch's owned dofs contiguous: cuddh_hip_helmholtz_apply_native --
+    # what HelmholtzOperator::gmres iterates on; same arithmetic, bitwise the same numbers, tests/test_gpu_parity.py)
+    t_nat = None
+    if A.has_native():
+        z, zy = torch.empty_like(x), torch.empty_like(x)
+        A.to_native(x, z)
+
+        class _Native:
+            def action(self, a, b):
+                A.action_native(z, zy)
+
+        t_nat = timed(_Native())
+        del z, zy
+    t = t_nat if t_nat is not None else t_ref
     # the two real operators the fused apply is made of, alone, same general layout (n_elem (metric + nb^2 4) + ndof 16)
     nb_, ne_ = fem.basis.n, mesh.n_elem()
     xr, yr = x[:ndof], y[:ndof]
@@ -675,21 +689,30 @@ def helmholtz_roofline(cd, torch, dev, fem, mesh, omega, ndof):
     # profiler on itself) by profiles/tools/pmc_traffic.sh and committed under profiles/rNN/helm_pmc_traffic.json.  It is
     # quoted only when that record was taken for this mesh AND this kernel instantiation; `traffic_source` says where it
     # comes from, so a stale record cannot pass for a measurement of this run.
-    traffic, traffic_source = None, "no committed PMC record for this mesh and kernel"
+    traffic, traffic_source = None, "no committed PMC record for this mesh, kernel and vector ordering"
     nx_now = int(round(math.sqrt(mesh.n_elem())))
     kernel_now = A.kernel()
+    ordering_now = "native" if t_nat is not None else "reference"
     for pmc in sorted((ROOT / "profiles").glob("r*/helm_pmc_traffic.json"), reverse=True):
         rec = json.loads(pmc.read_text())
-        if rec.get("nx") == nx_now and rec.get("nb") == fem.basis.n and rec.get("kernel") == kernel_now:
+        if rec.get("nx") == nx_now and rec.get("nb") == fem.basis.n and rec.get("kernel") == kernel_now and rec.get("ordering", "reference") == ordering_now:
             traffic = rec["traffic_bytes_per_apply"]
-            traffic_source = {"file": str(pmc.relative_to(ROOT)), "kernel": rec["kernel"], "collected_at_commit": rec.get("commit"),
+            traffic_source = {"file": str(pmc.relative_to(ROOT)), "kernel": rec["kernel"], "ordering": ordering_now, "collected_at_commit": rec.get("commit"),
                               "how": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 corrections as in "
                                      "MI355X_MICROARCH.md; NOT measured in this run"}
             break
     best_stream = max(copy_gbs, read_gbs)
+    ref_gbs = b_alg / t_ref / 1e9
     return {
         "bound": "hbm",
-        "kernel": (kernel_now + " + helm_border_kernel (fused complex Helmholtz apply)") if A.fused() else "unfused operator sequence",
+        "kernel": (kernel_now + (" on plan-native vectors + helm_border_native_kernel" if t_nat is not None else " + helm_border_kernel")
+                   + " (fused complex Helmholtz apply)") if A.fused() else "unfused operator sequence",
+        "vector_ordering": ("plan-native: vectors as (u, v) pairs, a patch's owned dofs contiguous (cuddh_hip_helmholtz_apply_native; what "
+                            "HelmholtzOperator::gmres iterates on, permuted once at entry and exit); scored against the SAME algorithmic bytes"
+                            if t_nat is not None else "reference: [u; v] in H1Space numbering"),
+        # the drop-in entry point (Operator::action on reference-ordered vectors), same plan, same run
+        "reference_ordering": {"kernel": kernel_now + " + helm_border_kernel", "seconds_per_apply": t_ref, "achieved": ref_gbs, "unit": "GB/s",
+                               "frac": ref_gbs / HBM_PEAK_GBS, "layout_bytes": A.bytes_per_apply(True)},
         "achieved": gbs,
         "peak": HBM_PEAK_GBS,
         "unit": "GB/s",
@@ -697,7 +720,7 @@ def helmholtz_roofline(cd, torch, dev, fem, mesh, omega, ndof):
         "traffic": traffic,
         "traffic_source": traffic_source,
         "algorithmic_bytes": b_alg,
-        "layout_bytes": A.bytes_per_apply(True),
+        "layout_bytes": A.bytes_native() if t_nat is not None else A.bytes_per_apply(True),
         "seconds_per_apply": t,
         "complex_dof_per_s": ndof / t,
         # measured in this run (GB/s): what plain streams reach on this box; reference points, not bounds

@@ -137,6 +137,10 @@ _sig("cuddh_hip_helmholtz_plan_create", ci, C.POINTER(vp), ci, ci, ci, vp, vp, c
 _sig("cuddh_hip_helmholtz_plan_destroy", ci, vp)
 _sig("cuddh_hip_helmholtz_apply", ci, vp, cd, vp, vp, vp)
 _sig("cuddh_hip_helmholtz_plan_bytes", cs, vp, ci)
+_sig("cuddh_hip_helmholtz_plan_has_native", ci, vp)
+_sig("cuddh_hip_helmholtz_to_native", ci, vp, vp, vp, vp)
+_sig("cuddh_hip_helmholtz_from_native", ci, vp, vp, vp, vp)
+_sig("cuddh_hip_helmholtz_apply_native", ci, vp, cd, vp, vp, vp)
 _sig("cuddh_hip_helmholtz_plan_describe", ci, vp, vp, ci)
 _sig("cuddh_hip_helmholtz_plan_read_stamps", ci, vp, vp, ci)
 _sig("cuddh_hip_operator_plan_create", ci, C.POINTER(vp), ci, ci, ci, ci, vp, vp, ci, vp, vp, vp)
@@ -211,6 +215,10 @@ _sig("cuddh_helmholtz_is_fused", ci, vp)
 _sig("cuddh_helmholtz_read_stamps", ci, vp, vp, ci)
 _sig("cuddh_operator_kernel_name", ci, vp, vp, ci)
 _sig("cuddh_helmholtz_bytes", cs, vp, ci)
+_sig("cuddh_helmholtz_has_native", ci, vp)
+_sig("cuddh_helmholtz_to_native", ci, vp, vp, vp)
+_sig("cuddh_helmholtz_from_native", ci, vp, vp, vp)
+_sig("cuddh_helmholtz_apply_native", ci, vp, vp, vp)
 _sig("cuddh_linear_functional", ci, vp, ci, ci, cd, cd, ci, vp)
 _sig("cuddh_face_linear_functional", ci, vp, ci, ci, cd, cd, ci, vp)
 _sig("cuddh_nodal_values", ci, vp, ci, cd, vp)
@@ -238,6 +246,7 @@ _sig("cuddh_ddh_local_solution_listed", ci, vp, vp, ci, vp, vp, vp, ci)
 _sig("cuddh_ddh_local_solution", ci, vp, ci, ci, vp, vp, vp, ci)
 _sig("cuddh_ddh_table", C.c_longlong, vp, cp, vp, ci)
 _sig("cuddh_gmres_f64", ci, ci, vp, vp, vp, vp, ci, ci, cd, ci, cd, C.POINTER(SolverResult), vp, vp)
+_sig("cuddh_gmres_helmholtz", ci, vp, vp, vp, ci, ci, cd, ci, cd, C.POINTER(SolverResult), vp, vp)
 _sig("cuddh_gmres_ddh", ci, ci, vp, vp, vp, ci, ci, cd, ci, cd, C.POINTER(SolverResult), vp, vp)
 _sig("cuddh_gmres_callback", ci, ci, vp, ACTION_CB, vp, vp, ci, ci, ci, cd, ci, cd, C.POINTER(SolverResult), vp, vp)
 _sig("cuddh_gmres_callback_sharded", ci, ci, vp, ACTION_CB, vp, REDUCE_CB, vp, vp, ci, ci, ci, cd, ci, cd, C.POINTER(SolverResult), vp, vp)

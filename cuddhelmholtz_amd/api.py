@@ -344,6 +344,31 @@ class HelmholtzOperator(_Operator):
     def bytes_per_apply(self, actual: bool = False) -> int:
         return int(lib.cuddh_helmholtz_bytes(self._h, 1 if actual else 0))
 
+    # ---- plan-native vector ordering (cuddh_hip.h: cuddh_hip_helmholtz_apply_native)
+    def has_native(self) -> bool:
+        return bool(lib.cuddh_helmholtz_has_native(self._h))
+
+    def to_native(self, x, z):
+        N.check_capi(lib.cuddh_helmholtz_to_native(self._h, _ptr(x, "f64", self._n, "x"), _ptr(z, "f64", self._n, "z")), "HelmholtzOperator.to_native")
+
+    def from_native(self, z, y):
+        N.check_capi(lib.cuddh_helmholtz_from_native(self._h, _ptr(z, "f64", self._n, "z"), _ptr(y, "f64", self._n, "y")), "HelmholtzOperator.from_native")
+
+    def action_native(self, z_in, z_out):
+        N.check_capi(lib.cuddh_helmholtz_apply_native(self._h, _ptr(z_in, "f64", self._n, "z_in"), _ptr(z_out, "f64", self._n, "z_out")), "HelmholtzOperator.action_native")
+
+    def gmres(self, x, b, m: int, maxit: int, tol: float = 1e-6, verbose: int = 0, max_seconds: float = 6 * 60 * 60) -> "SolverOut":
+        """HelmholtzOperator::gmres: x, b in the reference ordering; iteration vectors in plan-native ordering when the plan has one"""
+        res = N.SolverResult()
+        h_res = np.zeros(maxit + 2)
+        h_time = np.zeros(maxit + 2)
+        N.check_capi(lib.cuddh_gmres_helmholtz(self._h, _ptr(x, "f64", self._n, "x"), _ptr(b, "f64", self._n, "b"), m, maxit, float(tol), verbose,
+                                               float(max_seconds), C.byref(res), _h(h_res), _h(h_time)), "HelmholtzOperator.gmres")
+        return _solver_out(res, h_res, h_time)
+
+    def bytes_native(self) -> int:
+        return int(lib.cuddh_helmholtz_bytes(self._h, 3))
+
     def bytes_affine(self) -> int:
         """SURVEY 8d's "affine" figure when the plan reads the stiffness metric from one uniform table (0 otherwise)"""
         return int(lib.cuddh_helmholtz_bytes(self._h, 2))

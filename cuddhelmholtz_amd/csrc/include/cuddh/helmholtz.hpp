@@ -8,6 +8,7 @@
 #include <cstddef>
 #include <string>
 
+#include "krylov.hpp"
 #include "operator.hpp"
 #include "operators.hpp"
 #include "spaces.hpp"
@@ -41,8 +42,22 @@ namespace cuddh
         /// kernel instantiation of the fused apply ("unfused" when it fell back to the separate operators)
         std::string kernel_name() const;
 
+        /// Plan-native vector ordering (cuddh_hip.h: cuddh_hip_helmholtz_apply_native).  A Krylov solver only needs the operator and
+        /// inner products, so it can keep its vectors in the order the kernel likes best -- pairs (u, v), a patch's owned dofs
+        /// contiguous -- and permute once at entry and exit.  has_native(): the plan offers it (lane form); to_native / from_native:
+        /// [u; v] <-> native (2 * size doubles each); action_native: action() on native vectors, bitwise the same numbers.
+        bool has_native() const;
+        void to_native(const double *x, double *z) const;
+        void from_native(const double *z, double *y) const;
+        void action_native(const double *z_in, double *z_out) const;
+        /// gmres(2 * fem.size(), x, this, b, m, maxit, tol, ...) with the iteration vectors in native ordering when the plan has one
+        /// (x and b stay in the reference ordering: they are permuted at entry and exit); the plain gmres() otherwise
+        solver_out gmres(double *x, const double *b, int m, int maxit, double tol = 1e-6, int verbose = 0, double max_seconds = 6 * 60 * 60) const;
+
         /// bytes per apply: algorithmic (SURVEY 8d formula) or as laid out by the plan
         std::size_t bytes_per_apply(bool actual) const;
+        /// bytes the native apply moves as laid out (0 without a native ordering)
+        std::size_t bytes_native() const;
         /// bytes of the "affine" form when the plan found the stiffness metric identical in every element
         /// (uniform meshes: it is then read from one small table instead of n_elem copies); 0 otherwise
         std::size_t bytes_affine() const;

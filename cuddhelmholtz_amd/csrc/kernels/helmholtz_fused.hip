@@ -78,6 +78,16 @@ struct cuddh_helmholtz_plan
     int pair_layout = 0; // metric slices stored as [pairs of values][64 lanes][2] (+ one single row): 16-byte loads (lane form)
     unsigned long long *stamps = nullptr; // CUDDH_HELM_STAMPS=1: [n_patches][8] phase time stamps (100 MHz) of the lane form
     size_t bytes_affine = 0; // algorithmic bytes of the affine form (0 when neither metric array is uniform)
+    // Plan-native vector ordering (lane-form plans; cuddh_hip_helmholtz_apply_native): a vector is an array of (u, v) PAIRS in the
+    // order [patch 0's owned dofs | patch 1's owned dofs | ... | patch-border dofs in shared_dof order], so a patch reads and writes
+    // its owned dofs with contiguous 16-byte accesses and needs index lists for its border dofs only.
+    int *own_off = nullptr;          // [n_patches + 1] native position of a patch's first owned dof; own_off[n_patches] = all owned dofs
+    int *bpos = nullptr;             // [n_patches][bstride] native position of the patch's border dofs (padded with the last entry)
+    int *bslot = nullptr;            // [n_patches][bstride] slot in `part` of the patch's border dofs
+    int bstride = 0;
+    int *global_of_native = nullptr; // [ndof] reference dof id at every native position (the permutation, for to / from native)
+    int n_owned = 0;
+    size_t bytes_native = 0; // bytes the native apply moves (layout figure, like bytes_actual)
 };
 
 namespace
@@ -135,6 +145,9 @@ namespace
         double *y, *part;
         unsigned long long *stamps; // diagnostic: phase time stamps per patch, or null
         int pair_mass;              // helm_patch_kernel: two mass slices per round trip
+        // plan-native vector ordering (helm_lane_kernel<..., NATIVE>): x, y and part are then arrays of (u, v) pairs
+        const int *own_off, *bpos, *bslot;
+        int bstride;
     };
 
     // Variants measured and dropped: software-pipelined slice loads, slices split between the half-waves
@@ -551,8 +564,10 @@ namespace
                 else
                 {
                     const int sl = -dest[j] - 1;
-                    A.part[sl] = result(i);
-                    A.part[A.n_slots + sl] = result(ML + i);
+                    dbl2_t r; // a slot is the pair (u, v): one 16-byte store, one 16-byte load in the border kernel
+                    r.x = result(i);
+                    r.y = result(ML + i);
+                    reinterpret_cast<dbl2_t *>(A.part)[sl] = r;
                 }
             }
         }
@@ -587,7 +602,11 @@ namespace
     // prefetch 662 us against 428 us for helm_patch_kernel.  A lone wavefront issues one vector instruction every 4 cycles
     // instead of every 2: the arithmetic of a patch (8 us at n_basis 4) takes twice as long and nothing hides it.  A register
     // ring of three / four slices in helm_mfma_kernel (n_basis 6-8) also lost (spills at 168 registers: 190 -> 335 us).
-    template <int NB, int NQS, int NQM, bool NT, bool UG, bool PRE = false>
+    // NATIVE: x and y are in the plan's own vector ordering (pairs (u, v); a patch's owned dofs contiguous, cuddh_helmholtz_plan):
+    // the gather of the owned dofs is one 16-byte load per dof at an address known at kernel entry -- no index list, no dependent
+    // index -> value round trip -- and their write-out one 16-byte store; only the border dofs (15 % of an 8 x 8-element patch
+    // at n_basis 4) go through lists (native position for the gather, slot for the write-out).
+    template <int NB, int NQS, int NQM, bool NT, bool UG, bool PRE = false, bool NATIVE = false>
     __global__ void __launch_bounds__(64, PRE ? 1 : (NB == 2 ? 5 : (NB == 3 ? 3 : 2))) helm_lane_kernel(HelmArgs A, const double *__restrict__ PS, const double *__restrict__ DS,
                                                               const double *__restrict__ PM, const double *__restrict__ PF,
                                                               const double *__restrict__ GU)
@@ -669,18 +688,66 @@ namespace
         double aW[PRE ? NQM : 1][NQM];
 
         constexpr int ROWS = 10; // 640 dofs per pass: an 8x8-element patch of n_basis 4 (625) in one
+        static_assert(!(NATIVE && PRE), "the native ordering is implemented for the chain form");
+        // native ordering: local dofs [0, nown) are this patch's owned dofs at native positions own0 + i; the border dofs behind
+        // them take their native position (gather) and their slot (write-out) from the patch's two short lists
+        int own0 = 0, nown = 0;
+        const int *bp = nullptr, *bs = nullptr;
+        if constexpr (NATIVE)
+        {
+            own0 = A.own_off[patch];
+            nown = A.own_off[patch + 1] - own0;
+            bp = A.bpos + (size_t)patch * A.bstride;
+            bs = A.bslot + (size_t)patch * A.bstride;
+        }
+        const int bcap = A.bstride - 1;
         // Where the write-out sends its results (slot_of: the global dof of an owned local dof, -(slot) - 1 for a border dof).
         // The plan numbers a patch's owned dofs first, so for the rows of 64 local dofs below j_own = own_count / 64 the
         // destination IS the gather index and slot_of is not read at all: only its tail is (the rows holding border dofs),
         // requested with the other indices at kernel entry when the registers allow (EARLY_DEST).
         const int *slot = A.slot_of + off;
-        const int j_own = A.own_count[patch] >> 6; // wave-uniform
+        const int j_own = NATIVE ? (nown >> 6) : (A.own_count[patch] >> 6); // wave-uniform
         int dest0[ROWS];
-        if constexpr (EARLY_DEST)
+        if constexpr (EARLY_DEST && !NATIVE)
 #pragma unroll
             for (int j = 0; j < ROWS; ++j)
                 if (j >= j_own)
                     dest0[j] = slot[min(64 * j + lane, cap)];
+        if constexpr (NATIVE) // the slots of the border rows ride on the first round trip, like the native positions below
+#pragma unroll
+            for (int j = 0; j < ROWS; ++j)
+                if (j >= j_own)
+                    dest0[j] = bs[max(0, min(64 * j + lane - nown, bcap))];
+        const dbl2_t *X2 = reinterpret_cast<const dbl2_t *>(A.x);
+        auto native_gather_pass = [&](int base)
+        {
+            int pos[ROWS];
+#pragma unroll
+            for (int j = 0; j < ROWS; ++j)
+            {
+                const int i = base + 64 * j + lane;
+                pos[j] = own0 + i; // rows of owned dofs: the address is known now
+                if (base + 64 * j + 63 >= nown)
+                    pos[j] = bp[max(0, min(i - nown, bcap))];
+            }
+            dbl2_t xv2[ROWS];
+#pragma unroll
+            for (int j = 0; j < ROWS; ++j)
+            {
+                const int i = base + 64 * j + lane;
+                xv2[j] = X2[i < nown ? own0 + i : pos[j]];
+            }
+#pragma unroll
+            for (int j = 0; j < ROWS; ++j)
+            {
+                const int i = base + 64 * j + lane;
+                if (i < nloc)
+                {
+                    xy[i] = xv2[j].x;
+                    xy[ML + i] = xv2[j].y;
+                }
+            }
+        };
         auto gather_pass = [&](int base, auto first)
         {
             constexpr bool WITH_METRIC = PRE && decltype(first)::value;
@@ -730,9 +797,17 @@ namespace
                 }
             }
         };
-        gather_pass(0, std::true_type{});
-        for (int base = 64 * ROWS; base < nloc; base += 64 * ROWS)
-            gather_pass(base, std::false_type{});
+        if constexpr (NATIVE)
+        {
+            for (int base = 0; base == 0 || base < nloc; base += 64 * ROWS)
+                native_gather_pass(base);
+        }
+        else
+        {
+            gather_pass(0, std::true_type{});
+            for (int base = 64 * ROWS; base < nloc; base += 64 * ROWS)
+                gather_pass(base, std::false_type{});
+        }
         __syncthreads();
         stamp(1); // x is in LDS
 
@@ -891,7 +966,7 @@ namespace
             mass_slice(NQM - 1, am);
         }
 
-        if constexpr (!EARLY_DEST) // (the owned rows re-read their gather indices: lines the gather brought on chip)
+        if constexpr (!EARLY_DEST && !NATIVE) // (the owned rows re-read their gather indices: lines the gather brought on chip)
 #pragma unroll
             for (int j = 0; j < ROWS; ++j)
                 dest0[j] = (j >= j_own ? slot : dofs)[min(64 * j + lane, nloc - 1)];
@@ -976,9 +1051,18 @@ namespace
                     for (int k = 0; k < NB; ++k)
                     {
                         fl[k] = fli[k];
-                        const int gd = dofs[fl[k]];
-                        wu[k] = A.x[gd];
-                        wv[k] = A.x[A.ndof + gd];
+                        if constexpr (NATIVE)
+                        {
+                            const dbl2_t t = X2[fl[k] < nown ? own0 + fl[k] : bp[fl[k] - nown]];
+                            wu[k] = t.x;
+                            wv[k] = t.y;
+                        }
+                        else
+                        {
+                            const int gd = dofs[fl[k]];
+                            wu[k] = A.x[gd];
+                            wv[k] = A.x[A.ndof + gd];
+                        }
                     }
                     for (int q = 0; q < nqF; ++q)
                     {
@@ -1017,6 +1101,29 @@ namespace
 
         stamp(5); // faces done
         // write out
+        if constexpr (NATIVE)
+        {
+            dbl2_t *Y2 = reinterpret_cast<dbl2_t *>(A.y), *P2 = reinterpret_cast<dbl2_t *>(A.part);
+            for (int base = 0; base < nloc; base += 64 * ROWS)
+            {
+#pragma unroll
+                for (int j = 0; j < ROWS; ++j)
+                {
+                    const int i = base + 64 * j + lane;
+                    if (i >= nloc)
+                        continue;
+                    dbl2_t r;
+                    r.x = xy[i];
+                    r.y = xy[ML + i];
+                    if (i < nown)
+                        Y2[own0 + i] = r; // 16 bytes per lane, 1 KiB contiguous per instruction
+                    else
+                        P2[base == 0 ? dest0[j] : bs[min(i - nown, bcap)]] = r;
+                }
+            }
+            stamp(6);
+            return;
+        }
         for (int base = 0; base < nloc; base += 64 * ROWS)
         {
             int dest[ROWS];
@@ -1037,8 +1144,10 @@ namespace
                 else
                 {
                     const int sl = -dest[j] - 1;
-                    A.part[sl] = xy[i];
-                    A.part[A.n_slots + sl] = xy[ML + i];
+                    dbl2_t r; // a slot is the pair (u, v)
+                    r.x = xy[i];
+                    r.y = xy[ML + i];
+                    reinterpret_cast<dbl2_t *>(A.part)[sl] = r;
                 }
             }
         }
@@ -1049,18 +1158,61 @@ namespace
                                                              const int *__restrict__ shared_off,
                                                              const double *__restrict__ part, double *__restrict__ y)
     {
+        const dbl2_t *p2 = reinterpret_cast<const dbl2_t *>(part); // a slot is the pair (u, v)
         for (int j = blockIdx.x * 256 + threadIdx.x; j < n_shared; j += gridDim.x * 256)
         {
             double su = 0.0, sv = 0.0;
             for (int t = shared_off[j]; t < shared_off[j + 1]; ++t)
             {
-                const int s = t; // the slots of one dof are contiguous, in patch order
-                su += part[s];
-                sv += part[n_slots + s];
+                const dbl2_t s = p2[t]; // the slots of one dof are contiguous, in patch order
+                su += s.x;
+                sv += s.y;
             }
             const int g = shared_dof[j];
             y[g] = su;
             y[ndof + g] = sv;
+        }
+    }
+
+    // native ordering: the border dofs are the tail of the vector, in shared_dof order -- contiguous 16-byte stores
+    __global__ void __launch_bounds__(256) helm_border_native_kernel(int n_shared, int n_owned, const int *__restrict__ shared_off,
+                                                                    const dbl2_t *__restrict__ part, dbl2_t *__restrict__ y)
+    {
+        for (int j = blockIdx.x * 256 + threadIdx.x; j < n_shared; j += gridDim.x * 256)
+        {
+            dbl2_t s = {0.0, 0.0};
+            for (int t = shared_off[j]; t < shared_off[j + 1]; ++t)
+            {
+                s.x += part[t].x; // the slots of one dof are contiguous, in patch order (the order helm_border_kernel sums in)
+                s.y += part[t].y;
+            }
+            y[n_owned + j] = s;
+        }
+    }
+
+    // reference ordering [u; v] <-> plan-native ordering (pairs), through the permutation global_of_native
+    __global__ void __launch_bounds__(256) to_native_kernel(int ndof, const int *__restrict__ global_of_native, const double *__restrict__ x,
+                                                           dbl2_t *__restrict__ z)
+    {
+        for (int n = blockIdx.x * 256 + threadIdx.x; n < ndof; n += gridDim.x * 256)
+        {
+            const int g = global_of_native[n];
+            dbl2_t t;
+            t.x = x[g];
+            t.y = x[ndof + g];
+            z[n] = t;
+        }
+    }
+
+    __global__ void __launch_bounds__(256) from_native_kernel(int ndof, const int *__restrict__ global_of_native, const dbl2_t *__restrict__ z,
+                                                             double *__restrict__ y)
+    {
+        for (int n = blockIdx.x * 256 + threadIdx.x; n < ndof; n += gridDim.x * 256)
+        {
+            const int g = global_of_native[n];
+            const dbl2_t t = z[n];
+            y[g] = t.x;
+            y[ndof + g] = t.y;
         }
     }
 
@@ -1215,13 +1367,25 @@ namespace
     }
 
     template <int NB, int NQS, int NQM>
-    void launch_patch(const cuddh_helmholtz_plan *p, const HelmArgs &A, hipStream_t st)
+    void launch_patch(const cuddh_helmholtz_plan *p, const HelmArgs &A, hipStream_t st, bool native = false)
     {
         if constexpr (NB <= 4)
             if (p->pe == 64 && p->lane_form)
             {
                 const size_t lds = (size_t)2 * p->max_loc * sizeof(double);
                 const dim3 grid(8 * A.xcd_chunk), block(64);
+                if (native)
+                {
+                    if (p->Gu && p->streaming)
+                        hipLaunchKernelGGL((helm_lane_kernel<NB, NQS, NQM, true, true, false, true>), grid, block, lds, st, A, p->PS, p->DS, p->PM, p->PF, p->Gu);
+                    else if (p->Gu)
+                        hipLaunchKernelGGL((helm_lane_kernel<NB, NQS, NQM, false, true, false, true>), grid, block, lds, st, A, p->PS, p->DS, p->PM, p->PF, p->Gu);
+                    else if (p->streaming)
+                        hipLaunchKernelGGL((helm_lane_kernel<NB, NQS, NQM, true, false, false, true>), grid, block, lds, st, A, p->PS, p->DS, p->PM, p->PF, p->Gu);
+                    else
+                        hipLaunchKernelGGL((helm_lane_kernel<NB, NQS, NQM, false, false, false, true>), grid, block, lds, st, A, p->PS, p->DS, p->PM, p->PF, p->Gu);
+                    return;
+                }
                 if (p->prefetch)
                 {
                     // whole-patch prefetch: one wavefront per SIMD, the patch's metric block requested up front
@@ -1292,6 +1456,10 @@ namespace
         A.part = p->part;
         A.stamps = p->stamps;
         A.pair_mass = p->pair_mass;
+        A.own_off = p->own_off;
+        A.bpos = p->bpos;
+        A.bslot = p->bslot;
+        A.bstride = p->bstride;
         return A;
     }
 
@@ -2175,7 +2343,7 @@ namespace
                 if (dest[j] >= 0)
                     A.y[(size_t)cmp * A.ndof + dest[j]] = xy[cmp * ML + i];
                 else
-                    A.part[(size_t)cmp * A.n_slots + (-dest[j] - 1)] = xy[cmp * ML + i];
+                    A.part[2 * (size_t)(-dest[j] - 1) + cmp] = xy[cmp * ML + i]; // a slot is the pair (u, v); this wavefront holds one component
             }
         }
     }
@@ -2271,7 +2439,7 @@ extern "C"
             return 0;
         void *ptrs[] = {p->own_count, p->dof_off, p->dof_list, p->slot_of, p->patch_nel, p->lidx, p->colour, p->Gp, p->aMp, p->Gu, p->au, p->Gm, p->Am, p->face_off,
                         p->face_lidx, p->face_id, p->face_col, p->PS, p->DS, p->PM, p->PF, p->shared_dof, p->shared_off,
-                        p->part, p->stamps};
+                        p->part, p->stamps, p->own_off, p->bpos, p->bslot, p->global_of_native};
         for (void *q : ptrs)
             if (q)
                 (void)hipFree(q);
@@ -2495,6 +2663,48 @@ extern "C"
             if (e && !err)
                 err = e;
         };
+        // ---- plan-native vector ordering (lane-form plans): owned dofs patch by patch, then the border dofs in shared_dof order
+        size_t native_list_entries = 0;
+        if (want_pairs && !mfma && pe == 64)
+        {
+            std::vector<int> own_off(n_patches + 1, 0);
+            for (int q = 0; q < n_patches; ++q)
+                own_off[q + 1] = own_off[q] + own_count[q];
+            const int n_owned = own_off[n_patches];
+            int bstride = 1;
+            for (int q = 0; q < n_patches; ++q)
+                bstride = std::max(bstride, dof_off[q + 1] - dof_off[q] - own_count[q]);
+            std::vector<int> bpos((size_t)n_patches * bstride, 0), bslot((size_t)n_patches * bstride, 0), g_of_n(ndof, -1);
+            for (int q = 0; q < n_patches; ++q)
+            {
+                const int nloc = dof_off[q + 1] - dof_off[q], nb_q = nloc - own_count[q];
+                for (int i = 0; i < own_count[q]; ++i)
+                    g_of_n[own_off[q] + i] = dof_list[dof_off[q] + i];
+                for (int t = 0; t < bstride; ++t)
+                {
+                    const int i = own_count[q] + std::min(t, std::max(nb_q - 1, 0));
+                    if (nb_q == 0)
+                        continue; // no border dofs: the padding is never read (clamped index 0, value 0 = a valid position)
+                    bpos[(size_t)q * bstride + t] = n_owned + shared_index[dof_list[dof_off[q] + i]];
+                    bslot[(size_t)q * bstride + t] = -slot_of[dof_off[q] + i] - 1;
+                }
+                native_list_entries += nb_q;
+            }
+            for (int j = 0; j < n_shared; ++j)
+                g_of_n[n_owned + j] = shared_dof[j];
+            bool perm_ok = n_owned + n_shared == ndof;
+            for (int n = 0; n < ndof && perm_ok; ++n)
+                perm_ok = g_of_n[n] >= 0;
+            if (perm_ok) // (a dof no element touches would break the permutation: such a space keeps the reference ordering only)
+            {
+                p->n_owned = n_owned;
+                p->bstride = bstride;
+                ok(upload(&p->own_off, own_off));
+                ok(upload(&p->bpos, bpos));
+                ok(upload(&p->bslot, bslot));
+                ok(upload(&p->global_of_native, g_of_n));
+            }
+        }
         ok(upload(&p->dof_off, dof_off));
         // Fixed stride for the per-patch lists (helm_lane_kernel, helm_patch_kernel, op_patch_kernel with one patch per wavefront):
         // segment p starts at p * max_loc and is padded with its last entry, so a kernel can request its first indices without
@@ -2637,6 +2847,10 @@ extern "C"
         p->bytes_actual = (size_t)nG * 8 + (size_t)nA * 8 + lidx.size() * 4 + colour.size() + dof_list.size() * (4 + 16) + dest_bytes + // dof (gather), x
                           exclusive * 16 + (size_t)n_slots * (16 + 16) + (size_t)n_shared * (16 + 8) +
                           (size_t)n_faces * ((size_t)nqF * 8 + (size_t)nb * 2 + 5);
+        if (p->own_off) // the native apply: no dof list for owned dofs, two short lists for the border dofs, x gathered once per touching patch
+            p->bytes_native = (size_t)nG * 8 + (size_t)nA * 8 + lidx.size() * 4 + colour.size() + (size_t)(n_patches + 1) * 4 + native_list_entries * 8 +
+                              dof_list.size() * 16 + exclusive * 16 + (size_t)n_slots * (16 + 16) + (size_t)n_shared * (16 + 4) +
+                              (size_t)n_faces * ((size_t)nqF * 8 + (size_t)nb * 2 + 5);
         if (p->Gu || p->au) // SURVEY 8d's "affine" figure: the uniform metric arrays are not traffic
             p->bytes_affine = p->bytes_alg - (size_t)n_elem * ((p->Gu ? (size_t)3 * nqS * nqS * 8 : 0) + (p->au ? (size_t)nqM * nqM * 8 : 0));
         if (mfma)
@@ -2828,6 +3042,54 @@ extern "C"
         return err;
     }
 
+    // ---- plan-native vector ordering (see cuddh_helmholtz_plan): for solvers that keep their vectors in the plan's order
+    int cuddh_hip_helmholtz_plan_has_native(const cuddh_helmholtz_plan *p) { return (p && p->own_off && p->lane_form && p->nb <= 4) ? 1 : 0; }
+
+    int cuddh_hip_helmholtz_to_native(const cuddh_helmholtz_plan *p, const double *x, double *z, void *stream)
+    {
+        if (!cuddh_hip_helmholtz_plan_has_native(p))
+            return static_cast<int>(hipErrorNotSupported);
+        hipLaunchKernelGGL(to_native_kernel, dim3(stream_grid(p->ndof, 256)), dim3(256), 0, as_stream(stream), p->ndof, p->global_of_native, x,
+                           reinterpret_cast<dbl2_t *>(z));
+        return launch_status();
+    }
+
+    int cuddh_hip_helmholtz_from_native(const cuddh_helmholtz_plan *p, const double *z, double *y, void *stream)
+    {
+        if (!cuddh_hip_helmholtz_plan_has_native(p))
+            return static_cast<int>(hipErrorNotSupported);
+        hipLaunchKernelGGL(from_native_kernel, dim3(stream_grid(p->ndof, 256)), dim3(256), 0, as_stream(stream), p->ndof, p->global_of_native,
+                           reinterpret_cast<const dbl2_t *>(z), y);
+        return launch_status();
+    }
+
+    int cuddh_hip_helmholtz_apply_native(const cuddh_helmholtz_plan *p, double omega, const double *z_in, double *z_out, void *stream)
+    {
+        if (!cuddh_hip_helmholtz_plan_has_native(p))
+            return static_cast<int>(hipErrorNotSupported);
+        if (z_in == z_out)
+            return static_cast<int>(hipErrorInvalidValue);
+        hipStream_t st = as_stream(stream);
+        HelmArgs A = plan_args(p, z_in, z_out);
+        A.omega = omega;
+        if (p->nb == 4)
+            launch_patch<4, 5, 8>(p, A, st, true);
+        else if (p->nb == 3)
+            launch_patch<3, 4, 6>(p, A, st, true);
+        else
+            launch_patch<2, 3, 5>(p, A, st, true);
+        int err = launch_status();
+        if (err)
+            return err;
+        if (p->n_shared > 0)
+        {
+            hipLaunchKernelGGL(helm_border_native_kernel, dim3(stream_grid(p->n_shared, 256)), dim3(256), 0, st, p->n_shared, p->n_owned, p->shared_off,
+                               reinterpret_cast<const dbl2_t *>(p->part), reinterpret_cast<dbl2_t *>(z_out));
+            err = launch_status();
+        }
+        return err;
+    }
+
     // diagnostic (CUDDH_HELM_STAMPS=1 at plan creation): copies the [n_patches][8] phase stamps of the last lane-form apply
     int cuddh_hip_helmholtz_plan_read_stamps(const cuddh_helmholtz_plan *p, unsigned long long *h_out, int n_patches)
     {
@@ -2865,6 +3127,6 @@ extern "C"
     {
         if (!p)
             return 0;
-        return actual == 2 ? p->bytes_affine : (actual ? p->bytes_actual : p->bytes_alg);
+        return actual == 3 ? p->bytes_native : (actual == 2 ? p->bytes_affine : (actual ? p->bytes_actual : p->bytes_alg));
     }
 }

@@ -511,8 +511,23 @@ extern "C"
         auto *h = static_cast<OpHandle *>(op);
         if (!h->helm)
             return 0;
-        return actual == 2 ? h->helm->bytes_affine() : h->helm->bytes_per_apply(actual != 0);
+        return actual == 3 ? h->helm->bytes_native() : (actual == 2 ? h->helm->bytes_affine() : h->helm->bytes_per_apply(actual != 0));
     }
+    int cuddh_helmholtz_has_native(void *op)
+    {
+        auto *h = static_cast<OpHandle *>(op);
+        return h->helm && h->helm->has_native() ? 1 : 0;
+    }
+    static HelmholtzOperator &helm_of(void *op)
+    {
+        auto *h = static_cast<OpHandle *>(op);
+        if (!h->helm)
+            throw std::runtime_error("not a Helmholtz operator");
+        return *h->helm;
+    }
+    int cuddh_helmholtz_to_native(void *op, const double *x, double *z) { return guarded([&] { helm_of(op).to_native(x, z); }); }
+    int cuddh_helmholtz_from_native(void *op, const double *z, double *y) { return guarded([&] { helm_of(op).from_native(z, y); }); }
+    int cuddh_helmholtz_apply_native(void *op, const double *z_in, double *z_out) { return guarded([&] { helm_of(op).action_native(z_in, z_out); }); }
 
     // ------------------------------------------------------------ functionals
     int cuddh_linear_functional(void *fem, int nq, int integrand, double param, double c, int accumulate, double *F)
@@ -789,6 +804,16 @@ extern "C"
             const Operator *A = static_cast<OpHandle *>(op)->op.get();
             solver_out o = precond ? gmres(n, x, A, b, static_cast<OpHandle *>(precond)->op.get(), m, maxit, tol, verbose, max_seconds)
                                    : gmres(n, x, A, b, m, maxit, tol, verbose, max_seconds);
+            fill_result(o, out, h_res, h_time);
+        });
+    }
+
+    int cuddh_gmres_helmholtz(void *op, double *x, const double *b, int m, int maxit, double tol, int verbose, double max_seconds,
+                              cuddh_solver_result *out, double *h_res, double *h_time)
+    {
+        return guarded([&]
+        {
+            solver_out o = helm_of(op).gmres(x, b, m, maxit, tol, verbose, max_seconds);
             fill_result(o, out, h_res, h_time);
         });
     }

@@ -97,6 +97,54 @@ namespace cuddh
         return buf;
     }
 
+    bool HelmholtzOperator::has_native() const { return plan && cuddh_hip_helmholtz_plan_has_native(plan); }
+
+    void HelmholtzOperator::to_native(const double *x, double *z) const
+    {
+        detail::check_hip(cuddh_hip_helmholtz_to_native(plan, x, z, stream()), "HelmholtzOperator::to_native");
+    }
+
+    void HelmholtzOperator::from_native(const double *z, double *y) const
+    {
+        detail::check_hip(cuddh_hip_helmholtz_from_native(plan, z, y, stream()), "HelmholtzOperator::from_native");
+    }
+
+    void HelmholtzOperator::action_native(const double *z_in, double *z_out) const
+    {
+        detail::check_hip(cuddh_hip_helmholtz_apply_native(plan, omega, z_in, z_out, stream()), "HelmholtzOperator::action_native");
+    }
+
+    namespace
+    {
+        class NativeView : public Operator
+        {
+        public:
+            explicit NativeView(const HelmholtzOperator &A_) : A(A_) {}
+            void action(const double *x, double *y) const override { A.action_native(x, y); }
+            void action(double, const double *, double *) const override { cuddh_error("HelmholtzOperator (native view): action(c, x, y) not implemented"); }
+
+        private:
+            const HelmholtzOperator &A;
+        };
+    } // namespace
+
+    solver_out HelmholtzOperator::gmres(double *x, const double *b, int m, int maxit, double tol, int verbose, double max_seconds) const
+    {
+        const int n = 2 * ndof;
+        if (!has_native())
+            return cuddh::gmres(n, x, this, b, m, maxit, tol, verbose, max_seconds);
+        host_device_dvec zx(n), zb(n);
+        double *d_zx = zx.device_write(), *d_zb = zb.device_write();
+        to_native(x, d_zx);
+        to_native(b, d_zb);
+        NativeView V(*this);
+        solver_out out = cuddh::gmres(n, d_zx, &V, d_zb, m, maxit, tol, verbose, max_seconds);
+        from_native(d_zx, x);
+        return out;
+    }
+
+    std::size_t HelmholtzOperator::bytes_native() const { return cuddh_hip_helmholtz_plan_bytes(plan, 3); }
+
     std::size_t HelmholtzOperator::bytes_affine() const { return cuddh_hip_helmholtz_plan_bytes(plan, 2); }
 
     std::size_t HelmholtzOperator::bytes_per_apply(bool actual) const

@@ -94,7 +94,12 @@ int cuddh_helmholtz_is_fused(void *op);
 int cuddh_operator_kernel_name(void *op, char *buf, int cap);
 /* diagnostic: phase time stamps of the last fused apply, see cuddh_hip_helmholtz_plan_read_stamps */
 int cuddh_helmholtz_read_stamps(void *op, unsigned long long *h_out, int n_patches);
-size_t cuddh_helmholtz_bytes(void *op, int actual); /* actual: 0 / 1 / 2 as cuddh_hip_helmholtz_plan_bytes */
+size_t cuddh_helmholtz_bytes(void *op, int actual); /* actual: 0 / 1 / 2 / 3 as cuddh_hip_helmholtz_plan_bytes */
+/* plan-native vector ordering of the fused operator (cuddh_hip.h: cuddh_hip_helmholtz_apply_native); vectors of 2 * ndof doubles */
+int cuddh_helmholtz_has_native(void *op);
+int cuddh_helmholtz_to_native(void *op, const double *x, double *z);
+int cuddh_helmholtz_from_native(void *op, const double *z, double *y);
+int cuddh_helmholtz_apply_native(void *op, const double *z_in, double *z_out);
 
 /* ---- load vectors with built-in integrands (device lambdas cannot cross a C ABI).
  * integrand: 0 two Gaussians of examples/DDH.cpp:61-72 (param = omega)
@@ -164,6 +169,9 @@ typedef struct cuddh_solver_result
 
 int cuddh_gmres_f64(int n, double *x, void *op, const double *b, void *precond /* or NULL */, int m, int maxit, double tol,
                     int verbose, double max_seconds, cuddh_solver_result *out, double *h_res, double *h_time);
+/* HelmholtzOperator::gmres: x, b in the reference ordering [u; v]; the iteration runs on plan-native vectors when the plan has them */
+int cuddh_gmres_helmholtz(void *op, double *x, const double *b, int m, int maxit, double tol, int verbose, double max_seconds,
+                          cuddh_solver_result *out, double *h_res, double *h_time);
 /* op: a DDH handle (f64 == 0: float vectors, f64 != 0: double vectors) */
 int cuddh_gmres_ddh(int n, void *x, void *ddh, const void *b, int m, int maxit, double tol, int verbose, double max_seconds,
                     cuddh_solver_result *out, double *h_res, double *h_time);

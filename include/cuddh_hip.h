@@ -172,7 +172,19 @@ int cuddh_hip_helmholtz_apply(const cuddh_helmholtz_plan *plan, double omega, co
  * 1 as actually laid out, 2 the "affine" figure when the plan found a metric array identical in every element (uniform
  * meshes: one copy read through scalar loads instead of one per element; 0 otherwise).  CUDDH_PLAN_AFFINE=0 in the
  * environment at plan creation keeps the general form (used to measure the general-geometry roofline on a uniform mesh). */
-size_t cuddh_hip_helmholtz_plan_bytes(const cuddh_helmholtz_plan *plan, int actual);
+size_t cuddh_hip_helmholtz_plan_bytes(const cuddh_helmholtz_plan *plan, int actual); /* 3: as laid out for the native apply below */
+/* Plan-native vector ordering (not in the reference: its vectors are always [u; v] in H1Space numbering).  For solvers that keep
+ * their iteration vectors in the plan's own order -- gmres() only needs an operator and inner products, both invariant under a
+ * permutation -- a vector z is an array of ndof (u, v) PAIRS ordered [patch 0's owned dofs | patch 1's ... | patch-border dofs],
+ * so the apply reads and writes a patch's owned dofs with contiguous 16-byte accesses and no index list.  has_native: 1 when the
+ * plan runs the lane form (helm_lane_kernel: n_basis 2-4, large plans); to_native / from_native are the permutation and its
+ * inverse (x, y: [u; v] of length 2 ndof; z: 2 ndof doubles); apply_native is cuddh_hip_helmholtz_apply on native vectors
+ * (z_in != z_out).  Same arithmetic in the same order per element and per dof: from_native(apply_native(to_native(x))) is
+ * bitwise cuddh_hip_helmholtz_apply(x). */
+int cuddh_hip_helmholtz_plan_has_native(const cuddh_helmholtz_plan *plan);
+int cuddh_hip_helmholtz_to_native(const cuddh_helmholtz_plan *plan, const double *x, double *z, void *stream);
+int cuddh_hip_helmholtz_from_native(const cuddh_helmholtz_plan *plan, const double *z, double *y, void *stream);
+int cuddh_hip_helmholtz_apply_native(const cuddh_helmholtz_plan *plan, double omega, const double *z_in, double *z_out, void *stream);
 /* which kernel instantiation the plan's apply launches, e.g. "helm_lane_kernel<4,5,8,NT=1,UG=0> pe=64" (tests assert
  * the form they mean to exercise; bench.py reports it instead of re-deriving the size rules) */
 int cuddh_hip_helmholtz_plan_describe(const cuddh_helmholtz_plan *plan, char *buf, int cap);

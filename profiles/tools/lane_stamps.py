@@ -1,5 +1,5 @@
 """Where a wavefront of the fused apply spends its life: phase time stamps (100 MHz clock) recorded by helm_lane_kernel with
-CUDDH_HELM_STAMPS=1.  usage: CUDDH_HELM_PRE=0|1 lane_stamps.py [nx=1024]"""
+CUDDH_HELM_STAMPS=1.  usage: CUDDH_HELM_PRE=0|1 lane_stamps.py [nx=1024] [native]   (native: the plan-native vector ordering)"""
 import ctypes as C
 import math
 import os
@@ -26,12 +26,14 @@ fs = cd.FaceSpace(fem, mesh.boundary_edges())
 A = cd.HelmholtzOperator(math.pi * nx / 32, torch.ones(n, dtype=torch.float64, device=dev), torch.ones(fs.size(), dtype=torch.float64, device=dev), fem, fs)
 x = torch.rand(2 * n, dtype=torch.float64, device=dev)
 y = torch.empty_like(x)
+native = len(sys.argv) > 2 and sys.argv[2] == "native"
+apply = A.action_native if native else A.action
 for _ in range(3):
-    A.action(x, y)
+    apply(x, y)
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
-A.action(x, y)
+apply(x, y)
 e1.record()
 torch.cuda.synchronize()
 n_patches = (nx // 8) ** 2
@@ -42,7 +44,7 @@ t = st.astype(np.float64) * 0.01  # microseconds
 t0 = t[:, 0].min()
 names = ["start -> x in LDS (indices, x gather, first metric requests)", "-> element values in registers", "-> slices done (metric round trips + arithmetic)",
          "-> colour phases done", "-> faces done", "-> write-out done (stores complete)"]
-print(f"kernel: {A.kernel()}   launch (with stamps): {e0.elapsed_time(e1) * 1e3:.1f} us, {n_patches} wavefronts")
+print(f"kernel: {A.kernel()}{' (native ordering)' if native else ''}   launch (with stamps): {e0.elapsed_time(e1) * 1e3:.1f} us, {n_patches} wavefronts")
 print(f"first start {0.0:.1f} us, last start {t[:, 0].max() - t0:.1f} us, last end {t[:, 6].max() - t0:.1f} us")
 d = np.diff(t[:, :7], axis=1)
 for k, name in enumerate(names):

@@ -1,5 +1,5 @@
 """Runs one hot kernel a few times (for rocprofv3 counter passes).
-usage: run_kernel.py helm|stiff|mass|ddh NX [REPS] [KERNEL] [NB=4] [REFINE]
+usage: run_kernel.py helm|helmn|stiff|mass|ddh NX [REPS] [KERNEL] [NB=4] [REFINE]      (helmn: the fused apply on plan-native vectors)
 REFINE >= 0: the reference's unstructured fixture refined REFINE times instead of uniform_rect(NX) (NX is then ignored).
 Prints the kernel instantiation the operator launches (cuddh_hip_helmholtz_plan_describe)."""
 import math
@@ -29,14 +29,15 @@ else:
 fem = cd.H1Space(mesh, cd.Basis(nb))
 ndof = fem.size()
 print("elements", mesh.n_elem(), "n_basis", nb, "ndof", ndof)
-if which == "helm":
+if which in ("helm", "helmn"):
     fs = cd.FaceSpace(fem, mesh.boundary_edges())
     A = cd.HelmholtzOperator(omega, torch.ones(ndof, dtype=torch.float64, device=dev), torch.ones(fs.size(), dtype=torch.float64, device=dev), fem, fs)
     x = torch.rand(2 * ndof, dtype=torch.float64, device=dev)
     y = torch.empty_like(x)
     for _ in range(reps):
-        A.action(x, y)
-    print("kernel:", A.kernel(), "| algorithmic bytes", A.bytes_per_apply(), "| layout bytes", A.bytes_per_apply(True))
+        (A.action_native if which == "helmn" else A.action)(x, y)
+    print("kernel:", A.kernel(), "(plan-native vectors)" if which == "helmn" else "", "| algorithmic bytes", A.bytes_per_apply(), "| layout bytes",
+          A.bytes_native() if which == "helmn" else A.bytes_per_apply(True))
 elif which in ("stiff", "mass"):
     op = cd.StiffnessMatrix(fem) if which == "stiff" else cd.MassMatrix(fem, 0.5 + torch.rand(ndof, dtype=torch.float64, device=dev))
     x = torch.rand(ndof, dtype=torch.float64, device=dev)

@@ -490,6 +490,79 @@ def test_fused_helmholtz_apply(cuda, kind, nx, nb):
     assert A.bytes_per_apply() > 0 and A.bytes_per_apply(actual=True) > 0
 
 
+@pytest.mark.parametrize("affine", ["0", "1"])
+@pytest.mark.parametrize("kind,nx", [("structured", 10), ("structured", 37), ("unstructured", 0), ("refined", 2)])
+@pytest.mark.parametrize("nb", [2, 3, 4])
+def test_fused_helmholtz_apply_native_ordering(cuda, monkeypatch, kind, nx, nb, affine):
+    """The lane form of the fused apply on vectors in the PLAN'S OWN ordering (pairs (u, v); a patch's owned dofs contiguous;
+    include/cuddh_hip.h: cuddh_hip_helmholtz_apply_native): against the oracle through the permutation, and bitwise against
+    the reference-ordering apply (same arithmetic, same order per element and per dof); gmres() on the native vectors takes the
+    same iterations as on the reference ordering.  The lane form is forced (CUDDH_HELM_LANE=1: its size rule would pick
+    helm_patch_kernel for meshes this small); general-geometry layout and, on the uniform meshes, the affine form."""
+    import torch
+
+    import cuddhelmholtz_amd as cd
+
+    monkeypatch.setenv("CUDDH_HELM_LANE", "1")
+    monkeypatch.setenv("CUDDH_PLAN_AFFINE", affine)
+    if kind == "refined":
+        xy, elems = load_unstructured_square()
+        pm = cd.Mesh2D.from_vertices(xy, elems).refined(nx)
+        om = oracle.Mesh(pm.vertices(), pm.elements())
+    else:
+        pm, om = meshes(kind, nx)
+    fem = cd.H1Space(pm, cd.Basis(nb))
+    d = oracle.Discretization(om, nb)
+    n = d.ndof
+    faces = pm.boundary_edges()
+    fs = cd.FaceSpace(fem, faces)
+    ofs = oracle.FaceSpaceO(d, list(faces))
+    rng = np.random.default_rng(50 + nb)
+    a2 = 0.5 + rng.random(n)
+    ax = 0.5 + rng.random(ofs.size)
+    omega = 7.0
+    A = cd.HelmholtzOperator(omega, to_dev(torch, a2, cuda), to_dev(torch, ax, cuda), fem, fs)
+    assert A.fused()
+    if affine == "1" and kind == "structured" and nb > 2:
+        # affine plans of n_basis 3, 4 run helm_patch_kernel (two wavefronts per patch): reference ordering only
+        assert A.kernel().startswith(f"helm_patch_kernel<{nb},") and not A.has_native()
+        return
+    assert A.kernel().startswith(f"helm_lane_kernel<{nb},") and A.has_native()
+    xh = rng.standard_normal(2 * n)
+    x = to_dev(torch, xh, cuda)
+    z = torch.full((2 * n,), 7.0, dtype=torch.float64, device=cuda)
+    A.to_native(x, z)
+    # a permutation: pairs (u_g, v_g), every dof exactly once
+    zp = z.cpu().numpy().reshape(n, 2)
+    key = lambda a: np.sort(a.view(np.complex128).ravel())  # noqa: E731
+    assert np.array_equal(key(np.ascontiguousarray(zp)), key(np.ascontiguousarray(np.stack([xh[:n], xh[n:]], axis=1))))
+    back = torch.zeros_like(x)
+    A.from_native(z, back)
+    assert torch.equal(back, x)
+    y = torch.full((2 * n,), 123.0, dtype=torch.float64, device=cuda)
+    A.action(x, y)
+    zy = torch.full((2 * n,), -5.0, dtype=torch.float64, device=cuda)
+    A.action_native(z, zy)
+    yn = torch.zeros_like(y)
+    A.from_native(zy, yn)
+    ref = oracle.helmholtz_apply(d, oracle.Stiffness(d), oracle.Mass(d, a2), oracle.FaceMass(ofs, ax), ofs, omega, xh)
+    assert rel(yn.cpu().numpy(), ref) < 1e-12
+    assert torch.equal(yn, y)
+    zy2 = torch.zeros_like(zy)
+    A.action_native(z, zy2)
+    assert torch.equal(zy, zy2)
+    assert 0 < A.bytes_native() < A.bytes_per_apply(actual=True)
+    # GMRES(10), two cycles: native iteration vectors vs reference ordering (the inner products sum in another order)
+    bh = rng.standard_normal(2 * n)
+    b = to_dev(torch, bh, cuda)
+    x1, x2 = torch.zeros_like(b), torch.zeros_like(b)
+    o1 = cd.gmres(2 * n, x1, A, b, 10, 3, 0.0)
+    o2 = A.gmres(x2, b, 10, 3, 0.0)
+    assert o1.num_matvec == o2.num_matvec
+    assert abs(o1.res_norm[-1] - o2.res_norm[-1]) <= 1e-10 * o1.res_norm[0]
+    assert rel(x2.cpu().numpy(), x1.cpu().numpy()) < 1e-9
+
+
 # ------------------------------------------------------------------ GMRES
 def test_gmres_toeplitz_callback(cuda):
     """tests/gmres.cpp:41-77 with a Python-side operator."""
