@@ -122,6 +122,8 @@ _sig("cuddh_hip_trace_pack_f32", ci, ci, ci, vp, vp, vp, ci, vp)
 _sig("cuddh_hip_trace_pack_f64", ci, ci, ci, vp, vp, vp, ci, vp)
 _sig("cuddh_hip_trace_unpack_f32", ci, ci, ci, vp, vp, vp, vp)
 _sig("cuddh_hip_trace_unpack_f64", ci, ci, ci, vp, vp, vp, vp)
+_sig("cuddh_hip_halo_pack_f64", ci, ci, ci, vp, vp, vp, ci, vp)
+_sig("cuddh_hip_halo_unpack_f64", ci, ci, ci, vp, vp, vp, ci, vp)
 _sig("cuddh_hip_csr_sum_f64", ci, ci, vp, vp, vp, vp, ci, vp)
 _sig("cuddh_hip_zero_indexed_f64", ci, ci, vp, vp, vp)
 _sig("cuddh_hip_element_metrics", ci, ci, ci, vp, vp, vp, vp, vp, vp)
@@ -235,6 +237,14 @@ class MultiGpuResult(C.Structure):
                 ("t_setup", cd), ("t_rhs", cd), ("t_gmres", cd), ("t_postprocess", cd), ("bytes_sent_per_action_rank0", C.c_longlong)]
 
 
+class HelmholtzMultiGpuResult(C.Structure):
+    _fields_ = [("success", ci), ("num_iter", ci), ("num_matvec", ci), ("n_res", ci), ("world", ci), ("used_rccl", ci),
+                ("t_setup", cd), ("t_apply", cd), ("t_gmres", cd), ("n_loc_max", C.c_longlong), ("n_halo_max", C.c_longlong),
+                ("halo_bytes_per_apply_max", C.c_longlong)]
+
+
+_sig("cuddh_helmholtz_multi_gpu", ci, vp, ci, cd, vp, vp, vp, vp, ci, ci, ci, ci, ci, cd, C.POINTER(HelmholtzMultiGpuResult), vp)
+_sig("cuddh_helmholtz_partition_query", ci, vp, vp, vp, ci, ci, ci, ci, vp)
 _sig("cuddh_ddh_solve_multi_gpu", ci, ci, ci, cd, vp, vp, vp, ci, ci, ci, cd, ci, C.POINTER(MultiGpuResult), vp)
 _sig("cuddh_trace_exchange_query", ci, vp, ci, ci, ci, ci, ci, ci, ci, vp)
 _sig("cuddh_ddh_rhs", ci, vp, vp, vp)

@@ -25,5 +25,6 @@
 #include "cuddh/ddh.hpp"
 #include "cuddh/helmholtz.hpp"
 #include "cuddh/multigpu.hpp"
+#include "cuddh/partition.hpp"
 
 #endif

@@ -69,6 +69,26 @@ namespace cuddh
     multi_gpu_result ddh_solve_multi_gpu(int nx, int nb, double omega, const double *h_a, const double *h_f, double *h_u, int world,
                                          int gmres_m, int gmres_maxit, float tol, int transport = 0, bool split_schedule = false,
                                          int grid_x = 0, int grid_y = 0);
+
+    struct helmholtz_multi_gpu_result
+    {
+        solver_out gmres;
+        double t_setup = 0, t_apply = 0, t_gmres = 0; // seconds, max over ranks (t_apply: per apply)
+        int world = 1;
+        bool used_rccl = false;
+        long long n_loc_max = 0, n_halo_max = 0, halo_bytes_per_apply_max = 0;
+    };
+
+    /// The fused complex Helmholtz operator of examples/Helmholtz.hpp:28-56 partitioned over `world` devices of this process
+    /// (partition.hpp: element partition, sub-mesh operators, two halo exchanges per apply through cuddh_hip_halo_pack / unpack
+    /// and grouped RCCL send / recv).  Mesh: n_pts vertices h_xy (2, n_pts), n_elem quadrilaterals h_elems (4, n_elem) as
+    /// Mesh2D::from_vertices takes them; Basis(nb); h_a2x (ndof) nodal a^2, h_ax (FaceSpace of all boundary edges) a -- HOST,
+    /// global numbering.  gmres_maxit == 0: h_y = A h_x ([u; v], 2 ndof each; the apply is then repeated `reps` times for
+    /// t_apply); gmres_maxit > 0: h_y = GMRES(gmres_m) solution of A y = h_x from y = 0, every inner product all-reduced.
+    /// transport as in ddh_solve_multi_gpu (0 RCCL, 1 RCCL also for one rank, 2 loopback ranks sharing device 0).
+    helmholtz_multi_gpu_result helmholtz_multi_gpu(int n_pts, const double *h_xy, int n_elem, const int *h_elems, int nb, double omega,
+                                                   const double *h_a2x, const double *h_ax, const double *h_x, double *h_y, int world,
+                                                   int transport = 0, int reps = 0, int gmres_m = 20, int gmres_maxit = 0, double tol = 1e-8);
 } // namespace cuddh
 
 #endif

@@ -457,6 +457,35 @@ namespace
         }
     }
 
+    // halo exchange of the partitioned operator apply: entries t and n_half + t of a local [u; v] vector travel as the PAIR
+    // (buf[2 i], buf[2 i + 1]), so the messages for several neighbours are contiguous pieces of one buffer packed by one launch
+    __global__ void __launch_bounds__(BLOCK) halo_pack_kernel(int n, int n_half, const int *__restrict__ ids, double *__restrict__ v, double2 *__restrict__ buf,
+                                                              int clear)
+    {
+        for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK)
+        {
+            const int t = ids[i];
+            buf[i] = make_double2(v[t], v[n_half + t]);
+            if (clear)
+            {
+                v[t] = 0.0;
+                v[n_half + t] = 0.0;
+            }
+        }
+    }
+
+    __global__ void __launch_bounds__(BLOCK) halo_unpack_kernel(int n, int n_half, const int *__restrict__ ids, const double2 *__restrict__ buf,
+                                                                double *__restrict__ v, int add)
+    {
+        for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK)
+        {
+            const int t = ids[i]; // the ids of one unpack are distinct: a dof has one owner and, per sender, appears once
+            const double2 b = buf[i];
+            v[t] = add ? v[t] + b.x : b.x;
+            v[n_half + t] = add ? v[n_half + t] + b.y : b.y;
+        }
+    }
+
     // y[r] = (accumulate ? y[r] : 0) + sum_{k in [off[r], off[r+1])} x[src[k]], the terms added in the order they are listed
     __global__ void __launch_bounds__(BLOCK) csr_sum_kernel(int n_rows, const int *__restrict__ off, const int *__restrict__ src, const double *__restrict__ x,
                                                             double *__restrict__ y, int accumulate)
@@ -589,6 +618,18 @@ extern "C"
     {
         if (n > 0)
             hipLaunchKernelGGL((trace_unpack_kernel<double>), dim3(stream_grid(n, BLOCK)), dim3(BLOCK), 0, as_stream(s), n, n_half, slot, buf, v);
+        return n > 0 ? launch_status() : 0;
+    }
+    int cuddh_hip_halo_pack_f64(int n, int n_half, const int *ids, double *v, double *buf, int clear, void *s)
+    {
+        if (n > 0)
+            hipLaunchKernelGGL(halo_pack_kernel, dim3(stream_grid(n, BLOCK)), dim3(BLOCK), 0, as_stream(s), n, n_half, ids, v, reinterpret_cast<double2 *>(buf), clear);
+        return n > 0 ? launch_status() : 0;
+    }
+    int cuddh_hip_halo_unpack_f64(int n, int n_half, const int *ids, const double *buf, double *v, int add, void *s)
+    {
+        if (n > 0)
+            hipLaunchKernelGGL(halo_unpack_kernel, dim3(stream_grid(n, BLOCK)), dim3(BLOCK), 0, as_stream(s), n, n_half, ids, reinterpret_cast<const double2 *>(buf), v, add);
         return n > 0 ? launch_status() : 0;
     }
     int cuddh_hip_csr_sum_f64(int n_rows, const int *off, const int *src, const double *x, double *y, int accumulate, void *s)

@@ -658,6 +658,64 @@ extern "C"
                 h_res[i] = r.gmres.res_norm[i];
         });
     }
+    int cuddh_helmholtz_multi_gpu(void *mesh, int nb, double omega, const double *h_a2x, const double *h_ax, const double *h_x, double *h_y,
+                                  int world, int transport, int reps, int m, int maxit, double tol, cuddh_helmholtz_multi_gpu_result *out, double *h_res)
+    {
+        return guarded([&]
+        {
+            const QuadMeshData g = mesh_data(*static_cast<Mesh2D *>(mesh));
+            const helmholtz_multi_gpu_result r = helmholtz_multi_gpu(g.n_pts(), g.xy.data(), g.n_elem(), g.elems.data(), nb, omega, h_a2x, h_ax, h_x, h_y,
+                                                                     world, transport, reps, m, maxit, tol);
+            out->success = r.gmres.success ? 1 : 0;
+            out->num_iter = r.gmres.num_iter;
+            out->num_matvec = r.gmres.num_matvec;
+            out->n_res = static_cast<int>(r.gmres.res_norm.size());
+            out->world = r.world;
+            out->used_rccl = r.used_rccl ? 1 : 0;
+            out->t_setup = r.t_setup;
+            out->t_apply = r.t_apply;
+            out->t_gmres = r.t_gmres;
+            out->n_loc_max = r.n_loc_max;
+            out->n_halo_max = r.n_halo_max;
+            out->halo_bytes_per_apply_max = r.halo_bytes_per_apply_max;
+            for (int i = 0; h_res && i < out->n_res && i < maxit + 2; ++i)
+                h_res[i] = r.gmres.res_norm[i];
+        });
+    }
+    int cuddh_helmholtz_partition_query(void *mesh, void *fem, void *fs, int rank, int world, int which, int peer, int *h_out)
+    {
+        int count = -1;
+        const int err = guarded([&]
+        {
+            const H1Space &f = *static_cast<H1Space *>(fem);
+            const HelmholtzPartition p = HelmholtzPartition::build(*static_cast<Mesh2D *>(mesh), f.basis(), f, *static_cast<FaceSpace *>(fs), rank, world);
+            static const std::vector<int> none;
+            const std::vector<int> *v = &none;
+            if (which == 0)
+                v = &p.my_elems;
+            else if (which == 1)
+                v = &p.l2g;
+            else if (which == 2)
+                v = &p.owned;
+            else if (which == 3)
+                v = &p.halo;
+            else if (which == 4 || which == 5)
+            {
+                const auto &m = which == 4 ? p.own_to : p.halo_from;
+                const auto it = m.find(peer);
+                if (it != m.end())
+                    v = &it->second;
+            }
+            else if (which == 6)
+                v = &p.face_l2g;
+            else if (which == 7)
+                v = &p.faces;
+            count = static_cast<int>(v->size());
+            if (h_out)
+                std::copy(v->begin(), v->end(), h_out);
+        });
+        return err ? -1 : count;
+    }
     int cuddh_trace_exchange_query(const int *h_B, int n_domains, int mx_fdof, int n_lambda, int rank, int world, int which, int peer,
                                    int *h_out)
     {

@@ -19,6 +19,9 @@
 
 #include "cuddh/basis.hpp"
 #include "cuddh/ddh.hpp"
+#include "cuddh/helmholtz.hpp"
+#include "cuddh/meshio.hpp"
+#include "cuddh/partition.hpp"
 #include "cuddh/launch.hpp"
 #include "cuddh/mesh.hpp"
 #include "cuddh/spaces.hpp"
@@ -227,13 +230,144 @@ namespace cuddh
             }
             bool failed = false;
             int n;
-            std::vector<const float *> box; // box[from * n + to]: device pointer of the message from -> to
+            std::vector<const void *> box; // box[from * n + to]: device pointer of the message from -> to
             std::vector<std::vector<double>> vals;
             std::mutex m;
             std::condition_variable cv;
             int arrived = 0;
             long generation = 0;
         };
+
+        // Runs body(rank) for rank 0 on the caller's thread and for the other ranks on their own threads.  One rank's failure ends
+        // the call on every rank: the loopback barrier is released with an error and the RCCL communicators are aborted
+        // (ncclCommAbort makes pending and later collectives on them return), so no thread stays blocked in a collective; the
+        // first rank's OWN error is re-thrown, not the "another rank failed" of the ranks it released.  The caller gets its launch
+        // stream and current device back whatever happens.
+        template <typename Body>
+        void run_ranks(int world, Loopback &loop_state, std::vector<ncclComm_t> &comms, Body body)
+        {
+            struct CallerState
+            {
+                hipStream_t st = stream();
+                int dev = 0;
+                CallerState() { (void)hipGetDevice(&dev); }
+                ~CallerState()
+                {
+                    set_stream(st);
+                    (void)hipSetDevice(dev);
+                }
+            } caller_state;
+            std::vector<std::exception_ptr> errors(world);
+            std::atomic<bool> any_failed{false};
+            std::mutex abort_once;
+            auto abort_all = [&]()
+            {
+                std::lock_guard<std::mutex> lock(abort_once);
+                if (any_failed.exchange(true))
+                    return;
+                loop_state.abort();
+                for (auto &c : comms)
+                    if (c)
+                    {
+                        (void)Rccl::get().CommAbort(c);
+                        c = nullptr;
+                    }
+            };
+            auto guarded = [&](int rank)
+            {
+                try
+                {
+                    body(rank);
+                }
+                catch (...)
+                {
+                    errors[rank] = std::current_exception();
+                    abort_all();
+                }
+                set_stream(nullptr); // the rank's streams are gone; this thread launches on no dead stream
+            };
+            std::vector<std::thread> threads;
+            for (int r = 1; r < world; ++r)
+                threads.emplace_back(guarded, r);
+            guarded(0);
+            for (auto &t : threads)
+                t.join();
+            for (auto &c : comms)
+                if (c)
+                    (void)Rccl::get().CommDestroy(c);
+            std::exception_ptr first;
+            for (const auto &e : errors)
+            {
+                if (!e)
+                    continue;
+                bool secondary = false;
+                try
+                {
+                    std::rethrow_exception(e);
+                }
+                catch (const std::exception &ex)
+                {
+                    secondary = std::strstr(ex.what(), "another rank failed") != nullptr;
+                }
+                catch (...)
+                {
+                }
+                if (!secondary)
+                {
+                    first = e;
+                    break;
+                }
+                if (!first)
+                    first = e;
+            }
+            if (first)
+                std::rethrow_exception(first);
+        }
+
+        std::vector<ncclComm_t> make_comms(int world, bool use_rccl)
+        {
+            std::vector<ncclComm_t> comms(world, nullptr);
+            if (use_rccl)
+            {
+                std::vector<int> devs(world);
+                for (int r = 0; r < world; ++r)
+                    devs[r] = r;
+                check_nccl(Rccl::get().CommInitAll(comms.data(), world, devs.data()), "ncclCommInitAll");
+            }
+            return comms;
+        }
+
+        // sum of `count` device scalars over the ranks, in place, ordered on `st`
+        void all_reduce_on(Loopback *loop, ncclComm_t comm, hipStream_t st, int rank, int world, void *d, size_t count, ncclDataType_t type)
+        {
+            if (loop)
+            {
+                const size_t bytes = count * (type == ncclDouble ? 8 : 4);
+                std::vector<char> mine(bytes);
+                detail::check_hip(cuddh_hip_copy_d2h_on(mine.data(), d, bytes, st), "loopback reduce");
+                detail::check_hip(cuddh_hip_stream_sync(st), "stream sync");
+                std::vector<double> &slot = loop->vals[rank];
+                slot.resize(count);
+                for (size_t i = 0; i < count; ++i)
+                    slot[i] = type == ncclDouble ? reinterpret_cast<const double *>(mine.data())[i] : reinterpret_cast<const float *>(mine.data())[i];
+                loop->barrier();
+                std::vector<double> sum(count, 0.0);
+                for (int r = 0; r < world; ++r) // rank order: every rank gets the same bits
+                    for (size_t i = 0; i < count; ++i)
+                        sum[i] += loop->vals[r][i];
+                loop->barrier(); // everybody has read the slots
+                for (size_t i = 0; i < count; ++i)
+                    if (type == ncclDouble)
+                        reinterpret_cast<double *>(mine.data())[i] = sum[i];
+                    else
+                        reinterpret_cast<float *>(mine.data())[i] = static_cast<float>(sum[i]);
+                detail::check_hip(cuddh_hip_copy_h2d_on(d, mine.data(), bytes, st), "loopback reduce");
+                detail::check_hip(cuddh_hip_stream_sync(st), "stream sync");
+                return;
+            }
+            if (comm)
+                check_nccl(Rccl::get().AllReduce(d, d, count, type, ncclSum, comm, st), "ncclAllReduce");
+        }
 
         // everything one device needs, built and used by that device's host thread only
         struct Rank
@@ -359,36 +493,7 @@ namespace cuddh
                                       "trace unpack");
             }
 
-            void all_reduce(void *d, size_t count, ncclDataType_t type) const
-            {
-                if (loop)
-                {
-                    const size_t bytes = count * (type == ncclDouble ? 8 : 4);
-                    std::vector<char> mine(bytes);
-                    detail::check_hip(cuddh_hip_copy_d2h_on(mine.data(), d, bytes, st), "loopback reduce");
-                    sync();
-                    std::vector<double> &slot = loop->vals[rank];
-                    slot.resize(count);
-                    for (size_t i = 0; i < count; ++i)
-                        slot[i] = type == ncclDouble ? reinterpret_cast<const double *>(mine.data())[i] : reinterpret_cast<const float *>(mine.data())[i];
-                    loop->barrier();
-                    std::vector<double> sum(count, 0.0);
-                    for (int r = 0; r < world; ++r) // rank order: every rank gets the same bits
-                        for (size_t i = 0; i < count; ++i)
-                            sum[i] += loop->vals[r][i];
-                    loop->barrier(); // everybody has read the slots
-                    for (size_t i = 0; i < count; ++i)
-                        if (type == ncclDouble)
-                            reinterpret_cast<double *>(mine.data())[i] = sum[i];
-                        else
-                            reinterpret_cast<float *>(mine.data())[i] = static_cast<float>(sum[i]);
-                    detail::check_hip(cuddh_hip_copy_h2d_on(d, mine.data(), bytes, st), "loopback reduce");
-                    sync();
-                    return;
-                }
-                if (comm)
-                    check_nccl(Rccl::get().AllReduce(d, d, count, type, ncclSum, comm, st), "ncclAllReduce");
-            }
+            void all_reduce(void *d, size_t count, ncclDataType_t type) const { all_reduce_on(loop, comm, st, rank, world, d, count, type); }
         };
 
         // (I - T) on the partitioned trace vectors of one rank
@@ -425,59 +530,20 @@ namespace cuddh
         const bool use_rccl = !loopback && (world > 1 || transport == 1);
         Loopback loop_state(world);
 
-        // rank 0 runs on the caller's thread: whatever happens below, the caller gets its launch stream and current device back
-        struct CallerState
-        {
-            hipStream_t st = stream();
-            int dev = 0;
-            CallerState() { (void)hipGetDevice(&dev); }
-            ~CallerState()
-            {
-                set_stream(st);
-                (void)hipSetDevice(dev);
-            }
-        } caller_state;
-
-        std::vector<ncclComm_t> comms(world, nullptr);
-        if (use_rccl)
-        {
-            std::vector<int> devs(world);
-            for (int r = 0; r < world; ++r)
-                devs[r] = r;
-            check_nccl(Rccl::get().CommInitAll(comms.data(), world, devs.data()), "ncclCommInitAll");
-        }
+        std::vector<ncclComm_t> comms = make_comms(world, use_rccl);
 
         multi_gpu_result res;
         res.world = world;
         res.used_rccl = use_rccl;
         std::vector<double> t_setup(world, 0), t_rhs(world, 0), t_gmres(world, 0), t_post(world, 0);
         std::vector<solver_out> outs(world);
-        std::vector<std::exception_ptr> errors(world);
         std::mutex host_out; // h_u is written by rank 0 only; the mutex guards nothing else
-        // One rank's failure must end the call on every rank: the loopback barrier is released with an error, RCCL communicators are
-        // aborted (ncclCommAbort makes pending and later collectives on them return), so no thread stays blocked in a collective.
-        std::atomic<bool> any_failed{false};
-        std::mutex abort_once;
-        auto abort_all = [&]()
-        {
-            std::lock_guard<std::mutex> lock(abort_once);
-            if (any_failed.exchange(true))
-                return;
-            loop_state.abort();
-            for (auto &c : comms)
-                if (c)
-                {
-                    (void)Rccl::get().CommAbort(c);
-                    c = nullptr;
-                }
-        };
         // test hook (tests/test_gpu_native_drivers.py): CUDDH_MULTIGPU_FAIL_RANK=r makes rank r throw after its right-hand side
         const char *fail_env = std::getenv("CUDDH_MULTIGPU_FAIL_RANK");
         const int fail_rank = fail_env ? std::atoi(fail_env) : -1;
 
         auto body = [&](int rank)
         {
-            try
             {
                 detail::check_hip(static_cast<int>(hipSetDevice(loopback ? 0 : rank)), "hipSetDevice");
                 Rank R;
@@ -573,57 +639,307 @@ namespace cuddh
                     std::memcpy(h_u, u.host_read(), sizeof(double) * 2 * ndof);
                 }
             }
-            catch (...)
-            {
-                errors[rank] = std::current_exception();
-                abort_all();
-            }
-            set_stream(nullptr); // R (streams, events, operators) is gone; this thread launches on no dead stream
         };
-
-        std::vector<std::thread> threads;
-        for (int r = 1; r < world; ++r)
-            threads.emplace_back(body, r);
-        body(0);
-        for (auto &t : threads)
-            t.join();
-        for (auto &c : comms)
-            if (c)
-                (void)Rccl::get().CommDestroy(c);
-        // report the first rank's own error, not the "another rank failed" of the ranks it released
-        std::exception_ptr first;
-        for (const auto &e : errors)
-        {
-            if (!e)
-                continue;
-            bool secondary = false;
-            try
-            {
-                std::rethrow_exception(e);
-            }
-            catch (const std::exception &ex)
-            {
-                secondary = std::strstr(ex.what(), "another rank failed") != nullptr;
-            }
-            catch (...)
-            {
-            }
-            if (!secondary)
-            {
-                first = e;
-                break;
-            }
-            if (!first)
-                first = e;
-        }
-        if (first)
-            std::rethrow_exception(first);
+        run_ranks(world, loop_state, comms, body);
 
         res.gmres = outs[0];
         res.t_setup = *std::max_element(t_setup.begin(), t_setup.end());
         res.t_rhs = *std::max_element(t_rhs.begin(), t_rhs.end());
         res.t_gmres = *std::max_element(t_gmres.begin(), t_gmres.end());
         res.t_postprocess = *std::max_element(t_post.begin(), t_post.end());
+        return res;
+    }
+    // ================================================================================== global operator apply over several devices
+    namespace
+    {
+        // One rank of the partitioned fused Helmholtz operator (partition.hpp): its sub-mesh operator plus the two halo exchanges.
+        struct HelmRank
+        {
+            int rank = 0, world = 1;
+            Loopback *loop = nullptr;
+            ncclComm_t comm = nullptr;
+            hipStream_t st = nullptr;
+            std::unique_ptr<Mesh2D> gmesh;
+            std::unique_ptr<Basis> basis;
+            std::unique_ptr<H1Space> gfem;
+            std::unique_ptr<FaceSpace> gfs;
+            HelmholtzPartition part;
+            std::unique_ptr<HelmholtzOperator> op;
+            // per exchange: concatenated local-dof lists (peers in increasing rank), the peers' (rank, count) pieces, one buffer each way
+            struct Lists
+            {
+                HostDeviceArray<int> ids;
+                std::vector<std::pair<int, int>> pieces; // (peer, number of dofs)
+                int total = 0;
+            } own, halo;
+            host_device_dvec sbuf, rbuf, xs;
+            HostDeviceArray<int> halo_all;
+
+            HelmRank() = default;
+            HelmRank(const HelmRank &) = delete;
+            ~HelmRank()
+            {
+                op.reset();
+                part = HelmholtzPartition();
+                gfs.reset();
+                gfem.reset();
+                if (st)
+                {
+                    (void)hipStreamSynchronize(st);
+                    (void)hipStreamDestroy(st);
+                }
+            }
+
+            static void concat(const std::map<int, std::vector<int>> &m, Lists &L)
+            {
+                for (const auto &kv : m)
+                {
+                    L.pieces.emplace_back(kv.first, static_cast<int>(kv.second.size()));
+                    L.total += static_cast<int>(kv.second.size());
+                }
+                L.ids.resize(std::max(L.total, 1));
+                int *h = L.ids.host_write();
+                int o = 0;
+                for (const auto &kv : m)
+                    for (const int l : kv.second)
+                        h[o++] = l;
+            }
+
+            void sync() const { detail::check_hip(cuddh_hip_stream_sync(st), "stream sync"); }
+
+            // sends `out` pieces of sbuf, receives `in` pieces into rbuf; a piece of k dofs is 2 k doubles (pairs (u, v))
+            void exchange(const Lists &out, const Lists &in)
+            {
+                const double *sb = sbuf.device_read();
+                double *rb = rbuf.device_write();
+                if (loop)
+                {
+                    sync(); // my messages are packed
+                    int o = 0;
+                    for (const auto &pc : out.pieces)
+                    {
+                        loop->box[static_cast<std::size_t>(rank) * world + pc.first] = sb + 2 * static_cast<std::size_t>(o);
+                        o += pc.second;
+                    }
+                    loop->barrier();
+                    o = 0;
+                    for (const auto &pc : in.pieces)
+                    {
+                        detail::check_hip(static_cast<int>(hipMemcpyAsync(rb + 2 * static_cast<std::size_t>(o), loop->box[static_cast<std::size_t>(pc.first) * world + rank],
+                                                                            sizeof(double) * 2 * pc.second, hipMemcpyDeviceToDevice, st)),
+                                          "loopback message");
+                        o += pc.second;
+                    }
+                    sync();
+                    loop->barrier(); // every message is delivered: the send buffer may be reused
+                    return;
+                }
+                check_nccl(Rccl::get().GroupStart(), "ncclGroupStart");
+                int so = 0, ro = 0;
+                auto s_it = out.pieces.begin();
+                auto r_it = in.pieces.begin();
+                for (int peer = 0; peer < world; ++peer)
+                {
+                    if (s_it != out.pieces.end() && s_it->first == peer)
+                    {
+                        check_nccl(Rccl::get().Send(sb + 2 * static_cast<std::size_t>(so), 2 * static_cast<size_t>(s_it->second), ncclDouble, peer, comm, st), "ncclSend");
+                        so += s_it->second;
+                        ++s_it;
+                    }
+                    if (r_it != in.pieces.end() && r_it->first == peer)
+                    {
+                        check_nccl(Rccl::get().Recv(rb + 2 * static_cast<std::size_t>(ro), 2 * static_cast<size_t>(r_it->second), ncclDouble, peer, comm, st), "ncclRecv");
+                        ro += r_it->second;
+                        ++r_it;
+                    }
+                }
+                check_nccl(Rccl::get().GroupEnd(), "ncclGroupEnd");
+            }
+
+            /// y = A x on this rank's owned entries: halo entries of x are fetched from their owners, those of y end zero
+            void apply(const double *x, double *y)
+            {
+                const int n_loc = part.n_loc;
+                double *d_xs = xs.device_write();
+                detail::check_hip(cuddh_hip_copy_d2d(d_xs, x, sizeof(double) * 2 * n_loc, st), "halo scratch");
+                if (world > 1)
+                {
+                    detail::check_hip(cuddh_hip_halo_pack_f64(own.total, n_loc, own.ids.device_read(), d_xs, sbuf.device_write(), 0, st), "halo pack x");
+                    exchange(own, halo);
+                    detail::check_hip(cuddh_hip_halo_unpack_f64(halo.total, n_loc, halo.ids.device_read(), rbuf.device_read(), d_xs, 0, st), "halo unpack x");
+                }
+                op->action(d_xs, y);
+                if (world > 1)
+                {
+                    detail::check_hip(cuddh_hip_halo_pack_f64(halo.total, n_loc, halo.ids.device_read(), y, sbuf.device_write(), 1, st), "halo pack y");
+                    exchange(halo, own);
+                    // one launch per sender, in rank order: a dof several ranks hold as halo receives its partial sums in a fixed order
+                    int o = 0;
+                    for (const auto &pc : own.pieces)
+                    {
+                        detail::check_hip(cuddh_hip_halo_unpack_f64(pc.second, n_loc, own.ids.device_read() + o, rbuf.device_read() + 2 * static_cast<std::size_t>(o), y, 1, st),
+                                          "halo unpack y");
+                        o += pc.second;
+                    }
+                }
+            }
+        };
+
+        class HelmShardOperator : public Operator
+        {
+        public:
+            explicit HelmShardOperator(HelmRank &r_) : r(r_) {}
+            void action(const double *x, double *y) const override { r.apply(x, y); }
+            void action(double, const double *, double *) const override { cuddh_error("partitioned Helmholtz operator: action(c, x, y) not implemented"); }
+
+        private:
+            HelmRank &r;
+        };
+
+        void helm_reduce_hook(void *user, void *d_scalars, int count, int is_f64)
+        {
+            HelmRank *r = static_cast<HelmRank *>(user);
+            all_reduce_on(r->loop, r->comm, r->st, r->rank, r->world, d_scalars, static_cast<size_t>(count), is_f64 ? ncclDouble : ncclFloat);
+        }
+    } // namespace
+
+    helmholtz_multi_gpu_result helmholtz_multi_gpu(int n_pts, const double *h_xy, int n_elem, const int *h_elems, int nb, double omega, const double *h_a2x,
+                                                   const double *h_ax, const double *h_x, double *h_y, int world, int transport, int reps, int gmres_m,
+                                                   int gmres_maxit, double tol)
+    {
+        int n_dev = 0;
+        detail::check_hip(static_cast<int>(hipGetDeviceCount(&n_dev)), "hipGetDeviceCount");
+        const bool loopback = transport == 2;
+        if (world < 1 || (!loopback && world > n_dev) || world > 64)
+            cuddh_error("helmholtz_multi_gpu error: need 1 <= world <= number of visible devices (one rank per GPU).");
+        const bool use_rccl = !loopback && (world > 1 || transport == 1);
+        Loopback loop_state(world);
+        std::vector<ncclComm_t> comms = make_comms(world, use_rccl);
+
+        helmholtz_multi_gpu_result res;
+        res.world = world;
+        res.used_rccl = use_rccl;
+        std::vector<double> t_setup(world, 0), t_apply(world, 0), t_gmres(world, 0);
+        std::vector<solver_out> outs(world);
+        std::vector<long long> n_loc(world, 0), n_halo(world, 0), halo_bytes(world, 0);
+        std::vector<std::vector<double>> pieces(world); // every rank's owned entries of the result, assembled by the caller's thread afterwards
+        std::vector<std::vector<int>> piece_dofs(world);
+        int ndof_global = 0;
+
+        auto body = [&](int rank)
+        {
+            detail::check_hip(static_cast<int>(hipSetDevice(loopback ? 0 : rank)), "hipSetDevice");
+            HelmRank R;
+            R.rank = rank;
+            R.world = world;
+            R.comm = comms[rank];
+            R.loop = (loopback && world > 1) ? &loop_state : nullptr;
+            detail::check_hip(static_cast<int>(hipStreamCreateWithFlags(&R.st, hipStreamNonBlocking)), "hipStreamCreate");
+            set_stream(R.st);
+
+            auto t0 = clk::now();
+            R.gmesh.reset(new Mesh2D(Mesh2D::from_vertices(n_pts, h_xy, n_elem, h_elems)));
+            R.basis.reset(new Basis(nb));
+            R.gfem.reset(new H1Space(*R.gmesh, *R.basis));
+            std::vector<int> bfaces;
+            for (int e = 0; e < R.gmesh->n_edges(); ++e)
+                if (R.gmesh->edge(e)->type == FaceType::BOUNDARY)
+                    bfaces.push_back(e);
+            R.gfs.reset(new FaceSpace(*R.gfem, static_cast<int>(bfaces.size()), bfaces.data()));
+            const int ndof = R.gfem->size();
+            if (rank == 0)
+                ndof_global = ndof;
+            R.part = HelmholtzPartition::build(*R.gmesh, *R.basis, *R.gfem, *R.gfs, rank, world);
+            const HelmholtzPartition &P = R.part;
+            const int nl = P.n_loc;
+            host_device_dvec a2(nl), ax(std::max(P.fs->size(), 1));
+            {
+                double *h = a2.host_write();
+                for (int l = 0; l < nl; ++l)
+                    h[l] = h_a2x[P.l2g[l]];
+                double *hf = ax.host_write();
+                for (int i = 0; i < P.fs->size(); ++i)
+                    hf[i] = h_ax[P.face_l2g[i]];
+            }
+            R.op.reset(new HelmholtzOperator(omega, a2.device_read(), ax.device_read(), *P.fem, *P.fs));
+            HelmRank::concat(P.own_to, R.own);
+            HelmRank::concat(P.halo_from, R.halo);
+            const int mx = std::max(std::max(R.own.total, R.halo.total), 1);
+            R.sbuf.resize(2 * mx);
+            R.rbuf.resize(2 * mx);
+            R.xs.resize(2 * nl);
+            n_loc[rank] = nl;
+            n_halo[rank] = static_cast<long long>(P.halo.size());
+            halo_bytes[rank] = 16LL * (R.own.total + R.halo.total); // sent per apply: x to the holders + partial sums to the owners
+
+            // local vectors: the owned entries of the global input, zero at halo entries
+            host_device_dvec x(2 * nl), y(2 * nl);
+            {
+                double *h = x.host_write();
+                std::fill(h, h + 2 * nl, 0.0);
+                for (const int l : P.owned)
+                {
+                    h[l] = h_x[P.l2g[l]];
+                    h[nl + l] = h_x[ndof + P.l2g[l]];
+                }
+            }
+            const double *d_x = x.device_read();
+            double *d_y = y.device_write();
+            R.sync();
+            t_setup[rank] = since(t0);
+
+            if (gmres_maxit > 0)
+            {
+                HelmShardOperator A(R);
+                const ScalarReduce red{helm_reduce_hook, &R};
+                zeros(2 * nl, d_y);
+                t0 = clk::now();
+                outs[rank] = (use_rccl || R.loop) ? gmres(2 * nl, d_y, &A, d_x, gmres_m, gmres_maxit, tol, 0, 6 * 60 * 60.0, red)
+                                                  : gmres(2 * nl, d_y, &A, d_x, gmres_m, gmres_maxit, tol, 0);
+                R.sync();
+                t_gmres[rank] = since(t0);
+            }
+            else
+            {
+                R.apply(d_x, d_y);
+                R.sync();
+                if (reps > 0)
+                {
+                    if (R.loop)
+                        R.loop->barrier();
+                    t0 = clk::now();
+                    for (int i = 0; i < reps; ++i)
+                        R.apply(d_x, d_y);
+                    R.sync();
+                    t_apply[rank] = since(t0) / reps;
+                }
+            }
+            const double *hy = y.host_read();
+            pieces[rank].resize(2 * P.owned.size());
+            piece_dofs[rank].resize(P.owned.size());
+            for (std::size_t i = 0; i < P.owned.size(); ++i)
+            {
+                piece_dofs[rank][i] = P.l2g[P.owned[i]];
+                pieces[rank][2 * i] = hy[P.owned[i]];
+                pieces[rank][2 * i + 1] = hy[nl + P.owned[i]];
+            }
+        };
+        run_ranks(world, loop_state, comms, body);
+
+        // every dof has exactly one owner: the result is the union of the ranks' owned entries
+        for (int r = 0; r < world; ++r)
+            for (std::size_t i = 0; i < piece_dofs[r].size(); ++i)
+            {
+                h_y[piece_dofs[r][i]] = pieces[r][2 * i];
+                h_y[ndof_global + piece_dofs[r][i]] = pieces[r][2 * i + 1];
+            }
+        res.gmres = outs[0];
+        res.t_setup = *std::max_element(t_setup.begin(), t_setup.end());
+        res.t_apply = *std::max_element(t_apply.begin(), t_apply.end());
+        res.t_gmres = *std::max_element(t_gmres.begin(), t_gmres.end());
+        res.n_loc_max = *std::max_element(n_loc.begin(), n_loc.end());
+        res.n_halo_max = *std::max_element(n_halo.begin(), n_halo.end());
+        res.halo_bytes_per_apply_max = *std::max_element(halo_bytes.begin(), halo_bytes.end());
         return res;
     }
 } // namespace cuddh

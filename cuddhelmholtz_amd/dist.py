@@ -127,6 +127,53 @@ def ddh_solve_multi_gpu(nx: int, nb: int, omega: float, h_a, h_f, world: int, m:
     return u, info
 
 
+def helmholtz_multi_gpu(mesh, nb: int, omega: float, h_a2x, h_ax, h_x, world: int, transport: int = 0, reps: int = 0, m: int = 20,
+                        maxit: int = 0, tol: float = 1e-8):
+    """The fused Helmholtz operator partitioned over `world` GPUs of this process through the C++ host
+    (cuddh::helmholtz_multi_gpu: element partition, sub-mesh operators, halo exchanges through the HIP pack / unpack kernels,
+    RCCL send / recv or -- transport 2 -- loopback ranks sharing device 0).  maxit == 0: returns (A h_x, info) and times `reps`
+    applies; maxit > 0: returns (GMRES(m) solution of A y = h_x, info).  Host arrays in the global numbering."""
+    import ctypes as C
+
+    import numpy as np
+
+    from . import _native as N
+
+    h_a2x = np.ascontiguousarray(h_a2x, dtype=np.float64)
+    h_ax = np.ascontiguousarray(h_ax, dtype=np.float64)
+    h_x = np.ascontiguousarray(h_x, dtype=np.float64)
+    y = np.zeros_like(h_x)
+    res = N.HelmholtzMultiGpuResult()
+    hist = np.zeros(maxit + 2)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    N.check_capi(N.lib.cuddh_helmholtz_multi_gpu(mesh._h, nb, float(omega), vp(h_a2x), vp(h_ax), vp(h_x), vp(y), world, transport, reps, m, maxit,
+                                                float(tol), C.byref(res), vp(hist)), "helmholtz_multi_gpu")
+    info = {k: getattr(res, k) for k, _ in N.HelmholtzMultiGpuResult._fields_}
+    info["res_norm"] = hist[: res.n_res].tolist()
+    return y, info
+
+
+def native_helmholtz_partition(mesh, fem, fs, rank: int, world: int):
+    """HelmholtzPartition::build of the C++ host as a dict of numpy arrays (host only; tests compare it with HelmholtzPartition)"""
+    import ctypes as C
+
+    import numpy as np
+
+    from . import _native as N
+
+    def q(which, peer=0):
+        n = N.lib.cuddh_helmholtz_partition_query(mesh._h, fem._h, fs._h, rank, world, which, peer, None)
+        if n < 0:
+            raise RuntimeError(N.last_error())
+        out = np.zeros(max(n, 1), dtype=np.int32)
+        N.lib.cuddh_helmholtz_partition_query(mesh._h, fem._h, fs._h, rank, world, which, peer, out.ctypes.data_as(C.c_void_p))
+        return out[:n].astype(np.int64)
+
+    return {"my_elems": q(0), "l2g": q(1), "owned": q(2), "halo": q(3), "face_l2g": q(6), "faces": q(7),
+            "own_to": {s: v for s in range(world) if s != rank and (v := q(4, s)).size},
+            "halo_from": {s: v for s in range(world) if s != rank and (v := q(5, s)).size}}
+
+
 def _runs(ids):
     """sorted integer ids -> list of half-open (begin, end) runs"""
     out = []
@@ -401,22 +448,6 @@ class NeighbourShardedDDH:
 # ---------------------------------------------------------------------------------------------------------------------
 # Global operator apply over several GPUs ("next"): element partition + halo exchange of shared dofs
 # ---------------------------------------------------------------------------------------------------------------------
-def _morton_keys(xy):
-    import numpy as np
-
-    lo, hi = xy.min(axis=0), xy.max(axis=0)
-    span = np.where(hi > lo, hi - lo, 1.0)
-    c = np.clip(((xy - lo) / span * 65535.0 + 0.5).astype(np.uint64), 0, 65535)
-
-    def spread(v):
-        v = v & np.uint64(0xFFFF)
-        for shift, mask in ((8, 0x00FF00FF), (4, 0x0F0F0F0F), (2, 0x33333333), (1, 0x55555555)):
-            v = (v | (v << np.uint64(shift))) & np.uint64(mask)
-        return v
-
-    return spread(c[:, 0]) | (spread(c[:, 1]) << np.uint64(1))
-
-
 class HelmholtzPartition:
     """Host-side description of one rank's share of the fused Helmholtz operator.
 
@@ -437,11 +468,9 @@ class HelmholtzPartition:
         I = fem.global_indices()  # (nb, nb, n_elem), reference layout
         n_elem, ndof = mesh.n_elem(), fem.size()
         xy, elems = mesh.vertices(), mesh.elements().astype(np.int64)
-        order = np.argsort(_morton_keys(xy[elems].mean(axis=1)), kind="stable")
-        elem_rank = np.empty(n_elem, dtype=np.int64)
-        for r in range(world):
-            a, b = partition(n_elem, r, world)
-            elem_rank[order[a:b]] = r
+        # compact, equally sized element sets: consecutive runs of the Morton order of the centroids (cuddh::partition_elements,
+        # the rule the C++ host's HelmholtzPartition uses too)
+        elem_rank = np.asarray(mesh.partition(world), dtype=np.int64)
         self.my_elems = np.flatnonzero(elem_rank == rank)
         if self.my_elems.size == 0:
             raise ValueError("HelmholtzPartition: more ranks than elements")

@@ -135,6 +135,23 @@ typedef struct cuddh_multi_gpu_result
  * rectangles of the subdomain grid; 0 = strips of block rows); csrc/include/cuddh/multigpu.hpp. */
 int cuddh_ddh_solve_multi_gpu(int nx, int nb, double omega, const double *h_a, const double *h_f, double *h_u, int world, int m,
                               int maxit, double tol, int force_rccl, cuddh_multi_gpu_result *out, double *h_res);
+/* ---- the fused Helmholtz operator (examples/Helmholtz.hpp:28-56) partitioned over the GPUs of one node from one process
+ * (csrc/include/cuddh/multigpu.hpp: helmholtz_multi_gpu; partition.hpp).  mesh: a Mesh2D handle; h_a2x (ndof), h_ax (FaceSpace of
+ * ALL boundary edges, in increasing edge id), h_x / h_y ([u; v], 2 ndof) HOST, global numbering.  maxit == 0: h_y = A h_x, then
+ * `reps` timed applies; maxit > 0: GMRES(m) solve of A y = h_x.  transport: 0 RCCL, 1 RCCL also for one rank, 2 loopback ranks
+ * (threads sharing device 0; a test transport). */
+typedef struct cuddh_helmholtz_multi_gpu_result
+{
+    int success, num_iter, num_matvec, n_res, world, used_rccl;
+    double t_setup, t_apply, t_gmres;
+    long long n_loc_max, n_halo_max, halo_bytes_per_apply_max;
+} cuddh_helmholtz_multi_gpu_result;
+int cuddh_helmholtz_multi_gpu(void *mesh, int nb, double omega, const double *h_a2x, const double *h_ax, const double *h_x, double *h_y,
+                              int world, int transport, int reps, int m, int maxit, double tol, cuddh_helmholtz_multi_gpu_result *out,
+                              double *h_res /* maxit + 2 or NULL */);
+/* lists of HelmholtzPartition::build for `rank` of `world` (host only): which = 0 my_elems, 1 l2g, 2 owned, 3 halo, 4 own_to[peer],
+ * 5 halo_from[peer], 6 face_l2g, 7 faces.  Returns the count (-1 on error); h_out may be NULL to ask for the count only. */
+int cuddh_helmholtz_partition_query(void *mesh, void *fem, void *fs, int rank, int world, int which, int peer, int *h_out);
 /* ownership / send / receive lists of the trace exchange for `rank` of `world` (host only; what both the C++ and the
  * Python multi-GPU hosts use).  which: 0 owned slots, 1 slots sent to `peer`, 2 slots received from `peer`, 3 / 4 the subdomains
  * of the boundary / interior launch of the split schedule.  Returns the

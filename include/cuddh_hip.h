@@ -110,6 +110,14 @@ int cuddh_hip_trace_pack_f32(int n, int n_half, const int *slot, float *v, float
 int cuddh_hip_trace_pack_f64(int n, int n_half, const int *slot, double *v, double *buf, int clear, void *stream);
 int cuddh_hip_trace_unpack_f32(int n, int n_half, const int *slot, const float *buf, float *v, void *stream);
 int cuddh_hip_trace_unpack_f64(int n, int n_half, const int *slot, const double *buf, double *v, void *stream);
+/* Halo exchange of the partitioned global operator apply (new: the reference is single-GPU; it partitions the operator of
+ * examples/Helmholtz.hpp:28-56).  Entries ids[i] and n_half + ids[i] of a local [u; v] vector v travel as the pair
+ * (buf[2 i], buf[2 i + 1]): the messages for several neighbours are contiguous pieces of ONE buffer and one launch packs them all.
+ * pack: buf <- v at ids and, with clear != 0, those entries of v are zeroed (partial sums handed to the owner).
+ * unpack: v at ids <- buf (add == 0: halo values of x arriving from their owners) or v at ids += buf (add != 0: partial sums of y
+ * arriving at the owner; ids of one call are distinct, messages from different senders are added in rank order -> reproducible). */
+int cuddh_hip_halo_pack_f64(int n, int n_half, const int *ids, double *v, double *buf, int clear, void *stream);
+int cuddh_hip_halo_unpack_f64(int n, int n_half, const int *ids, const double *buf, double *v, int add, void *stream);
 
 /* ------------------------------------------------------------------ element operators (fp64)
  * Shapes: P,D (nq,nb); I (nb,nb,n_elem); J (2,2,nq,nq,n_elem); detJ (nq,nq,n_elem);

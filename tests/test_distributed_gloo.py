@@ -373,3 +373,35 @@ def test_native_trace_exchange_plan_equals_python(nx, nb, world):
         boundary, interior = native_trace_exchange.last_split
         assert np.array_equal(boundary, sh._ids["boundary"]) and np.array_equal(interior, sh._ids["interior"])
         assert boundary.size % 8 == 0 or interior.size == 0 or world == 1
+
+
+@pytest.mark.parametrize("kind,nb", [("structured", 4), ("unstructured", 3), ("refined", 5)])
+def test_native_helmholtz_partition_equals_python(kind, nb, unstructured_square):
+    """cuddh::HelmholtzPartition (csrc/src/partition.cpp, what the C++ multi-device host of the global operator apply uses) against
+    dist.HelmholtzPartition (validated against the oracle above): same elements, same local -> global map, same ownership, the
+    same dofs in the same order in both exchanges, the same boundary faces -- for 1..5 ranks."""
+    import cuddhelmholtz_amd as cd
+    from cuddhelmholtz_amd.dist import HelmholtzPartition, native_helmholtz_partition
+
+    if kind == "structured":
+        pm = cd.Mesh2D.uniform_rect(9, -1.0, 1.0, 6, -1.0, 1.0)
+    else:
+        xy, elems = unstructured_square
+        pm = cd.Mesh2D.from_vertices(xy, elems)
+        if kind == "refined":
+            pm = pm.refined(1)
+    fem = cd.H1Space(pm, cd.Basis(nb))
+    fs = cd.FaceSpace(fem, pm.boundary_edges())
+    for world in (1, 2, 3, 5):
+        for r in range(world):
+            py = HelmholtzPartition(cd, pm, fem, fs, r, world)
+            cx = native_helmholtz_partition(pm, fem, fs, r, world)
+            assert np.array_equal(cx["my_elems"], py.my_elems)
+            assert np.array_equal(cx["l2g"], py.l2g)
+            assert np.array_equal(cx["owned"], py.owned) and np.array_equal(cx["halo"], py.halo)
+            assert np.array_equal(cx["faces"], py.faces) and np.array_equal(cx["face_l2g"], py.face_l2g)
+            assert sorted(cx["own_to"]) == sorted(py.own_to) and sorted(cx["halo_from"]) == sorted(py.halo_from)
+            for s in py.own_to:
+                assert np.array_equal(cx["own_to"][s], py.own_to[s])
+            for s in py.halo_from:
+                assert np.array_equal(cx["halo_from"][s], py.halo_from[s])

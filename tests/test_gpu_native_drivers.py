@@ -13,6 +13,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 ROOT = Path(__file__).resolve().parent.parent
+GOLDEN = ROOT / "tests" / "golden"
 EX = ROOT / "build" / "examples"
 
 
@@ -324,3 +325,52 @@ def test_multi_gpu_host_rank_failure_ends_the_call(cuda, monkeypatch, world, fai
     assert N.lib.cuddh_get_stream() == stream_before
     u, info = ddh_solve_multi_gpu(nx, nb, omega, h_a, h_f, world=world, m=20, maxit=50, tol=1e-4, force_rccl=2, split_schedule=split)
     assert info["success"] == 1 and np.isfinite(u).all()
+
+
+@pytest.mark.parametrize("kind,nb,world", [("structured", 4, 2), ("structured", 4, 3), ("structured", 3, 4), ("refined", 4, 2), ("refined", 5, 3),
+                                           ("refined", 6, 4), ("structured", 4, 1)])
+def test_multi_gpu_helmholtz_host_loopback_ranks(cuda, kind, nb, world):
+    """cuddh::helmholtz_multi_gpu (SURVEY 8e "global operator apply" in the C++ host): the fused Helmholtz operator partitioned
+    over `world` loopback ranks (host threads sharing the test GPU, one stream each; element partition, sub-mesh plans, the two
+    halo exchanges through cuddh_hip_halo_pack / unpack, partial sums added in rank order) against the single-device operator:
+    the apply to 1e-13, and a GMRES solve through the reduce hook against gmres() on the single-device operator."""
+    import torch
+
+    import cuddhelmholtz_amd as cd
+    from cuddhelmholtz_amd.dist import helmholtz_multi_gpu
+
+    if kind == "structured":
+        mesh = cd.Mesh2D.uniform_rect(24, -1.0, 1.0, 20, -1.0, 1.0)
+    else:
+        mesh = cd.Mesh2D.load(GOLDEN / "unstructured_square").refined(1)
+    fem = cd.H1Space(mesh, cd.Basis(nb))
+    n = fem.size()
+    fs = cd.FaceSpace(fem, mesh.boundary_edges())
+    rng = np.random.default_rng(100 + nb + world)
+    a2, ax = 0.5 + rng.random(n), 0.5 + rng.random(fs.size())
+    xh = rng.standard_normal(2 * n)
+    omega = 5.0
+    A = cd.HelmholtzOperator(omega, torch.from_numpy(a2).to(cuda), torch.from_numpy(ax).to(cuda), fem, fs)
+    x = torch.from_numpy(xh).to(cuda)
+    y = torch.empty_like(x)
+    A.action(x, y)
+    ref = y.cpu().numpy()
+    from cuddhelmholtz_amd import _native as N
+
+    stream_before = N.lib.cuddh_get_stream()
+    got, info = helmholtz_multi_gpu(mesh, nb, omega, a2, ax, xh, world=world, transport=2, reps=2)
+    assert N.lib.cuddh_get_stream() == stream_before
+    err = float(np.linalg.norm(got - ref) / np.linalg.norm(ref))
+    print(f"helmholtz_multi_gpu {kind} n_basis {nb}, {world} loopback ranks: apply vs single device {err:.2e}; "
+          f"largest share {info['n_loc_max']} dofs ({info['n_halo_max']} halo), {info['halo_bytes_per_apply_max']} B sent per apply")
+    assert info["world"] == world and not info["used_rccl"]
+    assert err < 1e-13
+    if world > 1:
+        assert info["n_halo_max"] > 0 and info["halo_bytes_per_apply_max"] > 0 and info["n_loc_max"] < n
+    # GMRES(15), 3 cycles on A y = x: partitioned vectors + all-reduced inner products vs the single-device solver
+    sol = torch.zeros_like(x)
+    out = cd.gmres(2 * n, sol, A, x, 15, 4, 0.0)
+    got, info = helmholtz_multi_gpu(mesh, nb, omega, a2, ax, xh, world=world, transport=2, m=15, maxit=4, tol=0.0)
+    assert info["num_matvec"] == out.num_matvec
+    assert abs(info["res_norm"][-1] - out.res_norm[-1]) <= 1e-9 * out.res_norm[0]
+    assert float(np.linalg.norm(got - sol.cpu().numpy()) / np.linalg.norm(sol.cpu().numpy())) < 1e-8
