@@ -33,58 +33,87 @@ namespace
 
     inline bool aligned16(const void *p) { return (reinterpret_cast<size_t>(p) & 15) == 0; }
 
+    // Access pattern of every streaming kernel here (profiles/r03/stream_copy_variants.txt, 1 GiB of doubles on MI355X): a
+    // workgroup works on contiguous TILES of UNROLL x 256 sixteen-byte vectors, a thread's UNROLL accesses 256 vectors (4 KiB)
+    // apart, and workgroups take tiles in order -- at any moment the chip reads one contiguous window.  A copy that way runs at
+    // 6.2 TB/s (read + write); the former grid-stride form, whose four accesses per thread were a whole grid apart, at 4.4.
+    // Vectors too large to stay in the 256 MB infinity cache anyway are read and written with the non-temporal hint.
+    constexpr int UNROLL = 4;
+    constexpr int TILE = UNROLL * BLOCK; // 16-byte vectors per tile
+    constexpr long long NT_BYTES = 64LL << 20;
+
+    template <bool NT, typename V>
+    __device__ inline V stream_load(const V *p)
+    {
+        if constexpr (NT)
+            return __builtin_nontemporal_load(p);
+        else
+            return *p;
+    }
+    template <bool NT, typename V>
+    __device__ inline void stream_store(V *p, const V &v)
+    {
+        if constexpr (NT)
+            __builtin_nontemporal_store(v, p);
+        else
+            *p = v;
+    }
+    inline int tile_grid(long long n_vectors, int cap)
+    {
+        long long g = (n_vectors + TILE - 1) / TILE;
+        if (g > cap)
+            g = cap;
+        return static_cast<int>(g < 1 ? 1 : g);
+    }
+
     // ---------------- y = f(x, y) element-wise; F is a functor T(T x, T y)
-    template <typename T, typename F, bool READ_X, bool READ_Y>
+    template <typename T, typename F, bool READ_X, bool READ_Y, bool NT>
     __global__ void __launch_bounds__(BLOCK) map_kernel(int n, const T *__restrict__ x, T *__restrict__ y, F f, int vectorised)
     {
         using V = typename Pack<T>::type;
+        using VE = T __attribute__((ext_vector_type(Pack<T>::N))); // (clang vector: what the non-temporal builtins take)
         constexpr int N = Pack<T>::N;
-        const int tid = blockIdx.x * BLOCK + threadIdx.x;
-        const int stride = gridDim.x * BLOCK;
+        static_assert(sizeof(V) == sizeof(VE), "16-byte vectors");
         int done = 0;
         if (vectorised)
         {
             const int nv = n / N;
-            int i = tid;
-            // four independent 16-byte accesses per stream in flight per thread, then the single-access remainder
-            for (; i + 3 * stride < nv; i += 4 * stride)
+            const int n_tiles = (nv + TILE - 1) / TILE;
+            const VE *xv = reinterpret_cast<const VE *>(x);
+            VE *yv = reinterpret_cast<VE *>(y);
+            for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x)
             {
-                V xv[4], yv[4];
+                const int base = tile * TILE + threadIdx.x;
+                VE a[UNROLL], b[UNROLL];
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
+                for (int u = 0; u < UNROLL; ++u)
                 {
-                    if (READ_X)
-                        xv[u] = reinterpret_cast<const V *>(x)[i + u * stride];
-                    if (READ_Y)
-                        yv[u] = reinterpret_cast<const V *>(y)[i + u * stride];
+                    const int i = base + u * BLOCK;
+                    if (i < nv)
+                    {
+                        if (READ_X)
+                            a[u] = stream_load<NT>(xv + i);
+                        if (READ_Y)
+                            b[u] = stream_load<NT>(yv + i);
+                    }
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
+                for (int u = 0; u < UNROLL; ++u)
                 {
-                    T *xe = reinterpret_cast<T *>(&xv[u]);
-                    T *ye = reinterpret_cast<T *>(&yv[u]);
+                    const int i = base + u * BLOCK;
+                    if (i < nv)
+                    {
+                        VE r;
 #pragma unroll
-                    for (int c = 0; c < N; ++c)
-                        ye[c] = f(READ_X ? xe[c] : T(0), READ_Y ? ye[c] : T(0));
-                    reinterpret_cast<V *>(y)[i + u * stride] = yv[u];
+                        for (int c = 0; c < N; ++c)
+                            r[c] = f(READ_X ? a[u][c] : T(0), READ_Y ? b[u][c] : T(0));
+                        stream_store<NT>(yv + i, r);
+                    }
                 }
-            }
-            for (; i < nv; i += stride)
-            {
-                V xv, yv;
-                if (READ_X)
-                    xv = reinterpret_cast<const V *>(x)[i];
-                if (READ_Y)
-                    yv = reinterpret_cast<const V *>(y)[i];
-                T *xe = reinterpret_cast<T *>(&xv);
-                T *ye = reinterpret_cast<T *>(&yv);
-#pragma unroll
-                for (int c = 0; c < N; ++c)
-                    ye[c] = f(READ_X ? xe[c] : T(0), READ_Y ? ye[c] : T(0));
-                reinterpret_cast<V *>(y)[i] = yv;
             }
             done = nv * N;
         }
+        const int tid = blockIdx.x * BLOCK + threadIdx.x, stride = gridDim.x * BLOCK;
         for (int i = done + tid; i < n; i += stride)
             y[i] = f(READ_X ? x[i] : T(0), READ_Y ? y[i] : T(0));
     }
@@ -95,8 +124,11 @@ namespace
         if (n <= 0)
             return 0;
         const int vec = aligned16(y) && (!RX || aligned16(x));
-        hipLaunchKernelGGL((map_kernel<T, F, RX, RY>), dim3(stream_grid(n, BLOCK, Pack<T>::N)), dim3(BLOCK), 0, as_stream(stream), n,
-                           x, y, f, vec);
+        const int g = tile_grid(n / Pack<T>::N, 1 << 20);
+        if (static_cast<long long>(n) * sizeof(T) >= NT_BYTES)
+            hipLaunchKernelGGL((map_kernel<T, F, RX, RY, true>), dim3(g), dim3(BLOCK), 0, as_stream(stream), n, x, y, f, vec);
+        else
+            hipLaunchKernelGGL((map_kernel<T, F, RX, RY, false>), dim3(g), dim3(BLOCK), 0, as_stream(stream), n, x, y, f, vec);
         return launch_status();
     }
 
@@ -169,64 +201,59 @@ namespace
         return s; // valid in thread 0
     }
 
-    // MODE 0: sum x*y   1: sum (x-y)^2
-    template <typename T, int MODE>
+    // MODE 0: sum x*y   1: sum (x-y)^2   2: sum x*x (one stream: y is not read)
+    template <typename T, int MODE, bool NT>
     __global__ void __launch_bounds__(BLOCK) reduce_stage1(int n, const T *__restrict__ x, const T *__restrict__ y, T *__restrict__ partial,
                                                            int vectorised)
     {
-        using V = typename Pack<T>::type;
+        using VE = T __attribute__((ext_vector_type(Pack<T>::N)));
         constexpr int N = Pack<T>::N;
-        const int tid = blockIdx.x * BLOCK + threadIdx.x;
-        const int stride = gridDim.x * BLOCK;
         T acc = T(0);
         int done = 0;
+        auto term = [&](T a, T b)
+        {
+            if (MODE == 0)
+                acc += a * b;
+            else if (MODE == 1)
+            {
+                const T d = a - b;
+                acc += d * d;
+            }
+            else
+                acc += a * a;
+        };
         if (vectorised)
         {
             const int nv = n / N;
-            auto term = [&](const V &xv, const V &yv)
+            const int n_tiles = (nv + TILE - 1) / TILE;
+            const VE *xv = reinterpret_cast<const VE *>(x), *yv = reinterpret_cast<const VE *>(y);
+            for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) // contiguous tiles, taken in order by the workgroups
             {
-                const T *xe = reinterpret_cast<const T *>(&xv);
-                const T *ye = reinterpret_cast<const T *>(&yv);
+                const int base = tile * TILE + threadIdx.x;
+                VE a[UNROLL], b[UNROLL];
 #pragma unroll
-                for (int c = 0; c < N; ++c)
+                for (int u = 0; u < UNROLL; ++u)
                 {
-                    if (MODE == 0)
-                        acc += xe[c] * ye[c];
-                    else
+                    const int i = base + u * BLOCK;
+                    if (i < nv)
                     {
-                        const T d = xe[c] - ye[c];
-                        acc += d * d;
+                        a[u] = stream_load<NT>(xv + i);
+                        if (MODE != 2)
+                            b[u] = stream_load<NT>(yv + i);
                     }
                 }
-            };
-            int i = tid;
-            for (; i + 3 * stride < nv; i += 4 * stride) // four independent accesses per stream in flight
-            {
-                V xv[4], yv[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
-                {
-                    xv[u] = reinterpret_cast<const V *>(x)[i + u * stride];
-                    yv[u] = reinterpret_cast<const V *>(y)[i + u * stride];
-                }
+                for (int u = 0; u < UNROLL; ++u)
+                    if (base + u * BLOCK < nv)
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    term(xv[u], yv[u]);
+                        for (int c = 0; c < N; ++c)
+                            term(a[u][c], MODE != 2 ? b[u][c] : T(0));
             }
-            for (; i < nv; i += stride)
-                term(reinterpret_cast<const V *>(x)[i], reinterpret_cast<const V *>(y)[i]);
             done = nv * N;
         }
+        const int tid = blockIdx.x * BLOCK + threadIdx.x, stride = gridDim.x * BLOCK;
         for (int i = done + tid; i < n; i += stride)
-        {
-            if (MODE == 0)
-                acc += x[i] * y[i];
-            else
-            {
-                const T d = x[i] - y[i];
-                acc += d * d;
-            }
-        }
+            term(x[i], MODE != 2 ? y[i] : T(0));
         const T s = block_sum(acc);
         if (threadIdx.x == 0)
             partial[blockIdx.x] = s;
@@ -246,12 +273,16 @@ namespace
     template <typename T, int MODE, bool SQRT>
     int launch_reduce(int n, const T *x, const T *y, T *result, void *ws, void *stream)
     {
+        if constexpr (MODE == 0)
+            if (x == y) // <x, x>: one stream instead of two (the same products, bit for bit)
+                return launch_reduce<T, 2, SQRT>(n, x, y, result, ws, stream);
         T *partial = static_cast<T *>(ws);
-        int g = stream_grid(n, BLOCK, 4 * Pack<T>::N);
-        if (g > MAX_PARTIALS)
-            g = MAX_PARTIALS;
+        const int g = tile_grid(n / Pack<T>::N, MAX_PARTIALS);
         const int vec = aligned16(x) && aligned16(y);
-        hipLaunchKernelGGL((reduce_stage1<T, MODE>), dim3(g), dim3(BLOCK), 0, as_stream(stream), n, x, y, partial, vec);
+        if (static_cast<long long>(n) * sizeof(T) >= NT_BYTES)
+            hipLaunchKernelGGL((reduce_stage1<T, MODE, true>), dim3(g), dim3(BLOCK), 0, as_stream(stream), n, x, y, partial, vec);
+        else
+            hipLaunchKernelGGL((reduce_stage1<T, MODE, false>), dim3(g), dim3(BLOCK), 0, as_stream(stream), n, x, y, partial, vec);
         hipLaunchKernelGGL((reduce_stage2<T, SQRT>), dim3(1), dim3(BLOCK), 0, as_stream(stream), g, partial, result);
         return launch_status();
     }
@@ -290,41 +321,46 @@ namespace
         int done = 0;
         if (vectorised)
         {
-            // three streams in, one out, 16 bytes per lane and access
+            // three streams in, one out, 16 bytes per lane and access; contiguous tiles taken in order (see the top of the file)
+            using VE = T __attribute__((ext_vector_type(Pack<T>::N)));
             const int nv = n / N;
-            auto one = [&](int i, V wv, const V &pv, const V &nvv)
+            const int n_tiles = (nv + TILE - 1) / TILE;
+            VE *wv = reinterpret_cast<VE *>(w);
+            const VE *pv = reinterpret_cast<const VE *>(vprev), *nvv = reinterpret_cast<const VE *>(vnext);
+            for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x)
             {
-                T *we = reinterpret_cast<T *>(&wv);
-                const T *pe = reinterpret_cast<const T *>(&pv), *ne = reinterpret_cast<const T *>(&nvv);
+                const int base = tile * TILE + threadIdx.x;
+                VE a[UNROLL], b[UNROLL], c[UNROLL];
 #pragma unroll
-                for (int c = 0; c < N; ++c)
+                for (int u = 0; u < UNROLL; ++u)
                 {
-                    if (vprev)
-                        we[c] -= h * pe[c];
-                    acc += we[c] * (vnext ? ne[c] : we[c]);
-                }
-                if (vprev)
-                    reinterpret_cast<V *>(w)[i] = wv;
-            };
-            int i = tid;
-            for (; i + stride < nv; i += 2 * stride) // two independent accesses per stream (three streams) in flight
-            {
-                V wv[2], pv[2], nvv[2];
-#pragma unroll
-                for (int u = 0; u < 2; ++u)
-                {
-                    wv[u] = reinterpret_cast<const V *>(w)[i + u * stride];
-                    pv[u] = vprev ? reinterpret_cast<const V *>(vprev)[i + u * stride] : wv[u];
-                    nvv[u] = vnext ? reinterpret_cast<const V *>(vnext)[i + u * stride] : wv[u];
+                    const int i = base + u * BLOCK;
+                    if (i < nv)
+                    {
+                        a[u] = wv[i];
+                        if (vprev)
+                            b[u] = pv[i];
+                        if (vnext)
+                            c[u] = nvv[i];
+                    }
                 }
 #pragma unroll
-                for (int u = 0; u < 2; ++u)
-                    one(i + u * stride, wv[u], pv[u], nvv[u]);
-            }
-            for (; i < nv; i += stride)
-            {
-                const V wv = reinterpret_cast<const V *>(w)[i];
-                one(i, wv, vprev ? reinterpret_cast<const V *>(vprev)[i] : wv, vnext ? reinterpret_cast<const V *>(vnext)[i] : wv);
+                for (int u = 0; u < UNROLL; ++u)
+                {
+                    const int i = base + u * BLOCK;
+                    if (i < nv)
+                    {
+#pragma unroll
+                        for (int e = 0; e < N; ++e)
+                        {
+                            if (vprev)
+                                a[u][e] -= h * b[u][e];
+                            acc += a[u][e] * (vnext ? c[u][e] : a[u][e]);
+                        }
+                        if (vprev)
+                            wv[i] = a[u];
+                    }
+                }
             }
             done = nv * N;
         }
@@ -368,15 +404,27 @@ namespace
         int done = 0;
         if (vectorised)
         {
+            using VE = T __attribute__((ext_vector_type(Pack<T>::N)));
             const int nv = n / N;
-            for (int i = tid; i < nv; i += stride)
+            const int n_tiles = (nv + TILE - 1) / TILE;
+            VE *wv = reinterpret_cast<VE *>(w);
+            for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x)
             {
-                V wv = reinterpret_cast<const V *>(w)[i];
-                T *we = reinterpret_cast<T *>(&wv);
+                const int base = tile * TILE + threadIdx.x;
+                VE a[UNROLL];
 #pragma unroll
-                for (int c = 0; c < N; ++c)
-                    we[c] = we[c] / nrm;
-                reinterpret_cast<V *>(w)[i] = wv;
+                for (int u = 0; u < UNROLL; ++u)
+                    if (base + u * BLOCK < nv)
+                        a[u] = wv[base + u * BLOCK];
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u)
+                    if (base + u * BLOCK < nv)
+                    {
+#pragma unroll
+                        for (int c = 0; c < N; ++c)
+                            a[u][c] = a[u][c] / nrm;
+                        wv[base + u * BLOCK] = a[u];
+                    }
             }
             done = nv * N;
         }
@@ -384,11 +432,7 @@ namespace
             w[i] = w[i] / nrm;
     }
 
-    inline int mgs_grid(int n)
-    {
-        int g = stream_grid(n, BLOCK, 4);
-        return g > MAX_PARTIALS ? MAX_PARTIALS : g;
-    }
+    inline int mgs_grid(int n) { return tile_grid(n / 2, MAX_PARTIALS); } // (n / 2: at least as many tiles as either precision has)
 
     template <typename T>
     int launch_mgs_stage(int n, T *w, const T *vprev, const T *vnext, const T *pin, T *pout, T *hout, void *stream)
@@ -556,8 +600,8 @@ extern "C"
 
     int cuddh_hip_dot_f64(int n, const double *x, const double *y, double *r, void *ws, void *s) { return launch_reduce<double, 0, false>(n, x, y, r, ws, s); }
     int cuddh_hip_dot_f32(int n, const float *x, const float *y, float *r, void *ws, void *s) { return launch_reduce<float, 0, false>(n, x, y, r, ws, s); }
-    int cuddh_hip_nrm2_f64(int n, const double *x, double *r, void *ws, void *s) { return launch_reduce<double, 0, true>(n, x, x, r, ws, s); }
-    int cuddh_hip_nrm2_f32(int n, const float *x, float *r, void *ws, void *s) { return launch_reduce<float, 0, true>(n, x, x, r, ws, s); }
+    int cuddh_hip_nrm2_f64(int n, const double *x, double *r, void *ws, void *s) { return launch_reduce<double, 2, true>(n, x, x, r, ws, s); }
+    int cuddh_hip_nrm2_f32(int n, const float *x, float *r, void *ws, void *s) { return launch_reduce<float, 2, true>(n, x, x, r, ws, s); }
     int cuddh_hip_sqdist_f64(int n, const double *x, const double *y, double *r, void *ws, void *s) { return launch_reduce<double, 1, false>(n, x, y, r, ws, s); }
     int cuddh_hip_sqdist_f32(int n, const float *x, const float *y, float *r, void *ws, void *s) { return launch_reduce<float, 1, false>(n, x, y, r, ws, s); }
 
