@@ -158,7 +158,8 @@ namespace
     // 18.0 us, 512^2 unchanged; at n_basis 5 it spills 35 registers at 3 wavefronts per SIMD: 421 -> 549 us, not used there.  A
     // double-buffered chain at 2 wavefronts per SIMD for n_basis 5 -- next slice requested before the current one is computed
     // -- compiled to 256 registers + 13 spilled with the requests sunk below the arithmetic again: 431 -> 450 us, removed)
-    template <int NB, int NQS, int NQM, bool NT, bool UG, int PEK, int MODE = 0>
+    // NATIVE: x and y in the plan's own vector ordering (pairs (u, v), a patch's owned dofs contiguous; see helm_lane_kernel)
+    template <int NB, int NQS, int NQM, bool NT, bool UG, int PEK, int MODE = 0, bool NATIVE = false>
     __global__ void __launch_bounds__(2 * PEK, (NB >= 5 ? (UG ? 2 : 3) : ((NB == 4 && !UG) ? 3 : 4))) helm_patch_kernel(HelmArgs A, const double *__restrict__ PS, const double *__restrict__ DS,
                                                            const double *__restrict__ PM, const double *__restrict__ PF,
                                                            const double *__restrict__ GU)
@@ -233,13 +234,58 @@ namespace
         // gather index, so the destination list is read for the tail rows only (see op_patch_kernel)
         const int own_rows = A.own_count[patch] / NTH;
         int dest0[ROWS];
-        if constexpr (EARLY)
+        if constexpr (EARLY && !NATIVE)
         {
 #pragma unroll
             for (int j = 0; j < ROWS; ++j)
                 if (j >= own_rows)
                     dest0[j] = slot[min(NTH * j + lane, cap)];
         }
+        // native ordering: local dofs [0, nown) are this patch's owned dofs at native positions own0 + i; the border dofs behind
+        // them take their native position (gather) and their slot (write-out) from the patch's two short lists
+        int own0 = 0, nown = 0;
+        const int *bp = nullptr, *bs = nullptr;
+        const int bcap = A.bstride - 1;
+        const dbl2_t *X2 = reinterpret_cast<const dbl2_t *>(A.x);
+        if constexpr (NATIVE)
+        {
+            own0 = A.own_off[patch];
+            nown = A.own_off[patch + 1] - own0;
+            bp = A.bpos + (size_t)patch * A.bstride;
+            bs = A.bslot + (size_t)patch * A.bstride;
+            for (int base = 0; base == 0 || base < nloc; base += NTH * ROWS)
+            {
+                int pos[ROWS];
+#pragma unroll
+                for (int j = 0; j < ROWS; ++j)
+                {
+                    const int i = base + NTH * j + lane;
+                    pos[j] = own0 + i;
+                    if (base + NTH * j + NTH - 1 >= nown) // (workgroup-uniform) a row that holds border dofs
+                        pos[j] = bp[max(0, min(i - nown, bcap))];
+                }
+                dbl2_t xv2[ROWS];
+#pragma unroll
+                for (int j = 0; j < ROWS; ++j)
+                {
+                    const int i = base + NTH * j + lane;
+                    xv2[j] = X2[i < nown ? own0 + i : pos[j]];
+                }
+#pragma unroll
+                for (int j = 0; j < ROWS; ++j)
+                {
+                    const int i = base + NTH * j + lane;
+                    if (i < nloc)
+                    {
+                        xs[i] = xv2[j].x;
+                        xs[ML + i] = xv2[j].y;
+                        ys[i] = 0.0;
+                        ys[ML + i] = 0.0;
+                    }
+                }
+            }
+        }
+        else
         for (int base = 0; base == 0 || base < nloc; base += NTH * ROWS) // (the first pass does not wait for nloc)
         {
             int gi[ROWS];
@@ -278,6 +324,10 @@ namespace
         const double *xc = xs + comp * ML;
         auto lix_of = [&](int n) -> int { return (n & 1) ? static_cast<int>(lpk[n >> 1] >> 16) : static_cast<int>(lpk[n >> 1] & 0xFFFFu); };
         const double keep = active ? 1.0 : 0.0;
+        // (n_basis 5, 3 wavefronts per SIMD: the 25-27 spilled registers are stored once before the slices and re-loaded once
+        // after them -- values the element phase does not touch.  Streaming the element's values from the LDS copy of x in every
+        // slice instead of holding them in registers removes 6 of them for 350 more LDS reads per lane: 768^2 a wash, irregular mesh
+        // 5 % slower; measured and removed, profiles/r03/nb5_ab.txt.)
         double u[NN], out[NN];
 #pragma unroll
         for (int n = 0; n < NN; ++n)
@@ -447,7 +497,7 @@ namespace
             }
         }
 
-        if constexpr (!EARLY)
+        if constexpr (!EARLY && !NATIVE)
         {
 #pragma unroll
             for (int j = 0; j < ROWS; ++j)
@@ -510,7 +560,13 @@ namespace
                     for (int k = 0; k < NB; ++k)
                     {
                         fl[k] = fli[k];
-                        w[k] = TWO ? xg[dofs[fl[k]]] : xo[fl[k]];
+                        if constexpr (NATIVE && TWO)
+                        {
+                            const dbl2_t t = X2[fl[k] < nown ? own0 + fl[k] : bp[fl[k] - nown]];
+                            w[k] = comp ? t.x : t.y; // the other component
+                        }
+                        else
+                            w[k] = TWO ? xg[dofs[fl[k]]] : xo[fl[k]];
                     }
                     for (int q = 0; q < nqF; ++q)
                     {
@@ -544,6 +600,21 @@ namespace
         if constexpr (TWO)
             __syncthreads(); // both accumulators complete
         auto result = [&](int i) -> double { return TWO ? xs[i] + ys[i] : ys[i]; };
+        if constexpr (NATIVE)
+        {
+            dbl2_t *Y2 = reinterpret_cast<dbl2_t *>(A.y), *P2 = reinterpret_cast<dbl2_t *>(A.part);
+            for (int i = lane; i < nloc; i += NTH)
+            {
+                dbl2_t r;
+                r.x = result(i);
+                r.y = result(ML + i);
+                if (i < nown)
+                    Y2[own0 + i] = r; // 16 bytes per lane, contiguous
+                else
+                    P2[bs[min(i - nown, bcap)]] = r;
+            }
+            return;
+        }
         for (int base = 0; base < nloc; base += NTH * ROWS)
         {
             int dest[ROWS]; // one index per dof: global dof (owned) or -(slot) - 1 (border)
@@ -1340,10 +1411,32 @@ namespace
     }
 
     template <int NB, int NQS, int NQM, int PEK>
-    void launch_patch_pe(const cuddh_helmholtz_plan *p, const HelmArgs &A, hipStream_t st)
+    void launch_patch_pe(const cuddh_helmholtz_plan *p, const HelmArgs &A, hipStream_t st, bool native = false)
     {
         const size_t lds = (size_t)4 * p->max_loc * sizeof(double);
         const dim3 grid(8 * A.xcd_chunk), block(2 * PEK);
+        if (native) // the same MODE as the reference-ordering launch below, so that the two orderings give bitwise the same numbers
+        {
+            constexpr bool CAN_PAIR_N = 2 * NQM <= 3 * NQS && NB <= 4;
+            if constexpr (CAN_PAIR_N)
+                if (!p->Gu && A.pair_mass)
+                {
+                    if (p->streaming)
+                        hipLaunchKernelGGL((helm_patch_kernel<NB, NQS, NQM, true, false, PEK, 1, true>), grid, block, lds, st, A, p->PS, p->DS, p->PM, p->PF, p->Gu);
+                    else
+                        hipLaunchKernelGGL((helm_patch_kernel<NB, NQS, NQM, false, false, PEK, 1, true>), grid, block, lds, st, A, p->PS, p->DS, p->PM, p->PF, p->Gu);
+                    return;
+                }
+            if (p->Gu && p->streaming)
+                hipLaunchKernelGGL((helm_patch_kernel<NB, NQS, NQM, true, true, PEK, 0, true>), grid, block, lds, st, A, p->PS, p->DS, p->PM, p->PF, p->Gu);
+            else if (p->Gu)
+                hipLaunchKernelGGL((helm_patch_kernel<NB, NQS, NQM, false, true, PEK, 0, true>), grid, block, lds, st, A, p->PS, p->DS, p->PM, p->PF, p->Gu);
+            else if (p->streaming)
+                hipLaunchKernelGGL((helm_patch_kernel<NB, NQS, NQM, true, false, PEK, 0, true>), grid, block, lds, st, A, p->PS, p->DS, p->PM, p->PF, p->Gu);
+            else
+                hipLaunchKernelGGL((helm_patch_kernel<NB, NQS, NQM, false, false, PEK, 0, true>), grid, block, lds, st, A, p->PS, p->DS, p->PM, p->PF, p->Gu);
+            return;
+        }
         // general layout, 2 NQM <= 3 NQS (n_basis 3 and 5): the mass phase takes two slices per round trip (PM)
         constexpr bool CAN_PAIR = 2 * NQM <= 3 * NQS && NB <= 4;
         if (p->Gu && p->streaming)
@@ -1410,9 +1503,9 @@ namespace
                 return;
             }
         if (p->pe == 64)
-            launch_patch_pe<NB, NQS, NQM, 64>(p, A, st);
+            launch_patch_pe<NB, NQS, NQM, 64>(p, A, st, native);
         else
-            launch_patch_pe<NB, NQS, NQM, 32>(p, A, st);
+            launch_patch_pe<NB, NQS, NQM, 32>(p, A, st, native);
     }
 
     // fused complex apply on the fp64 matrix cores (16-element batches)
@@ -1985,13 +2078,20 @@ namespace
     // 364 -> 256 us (n_basis 8) at 147k elements.  Both waves read the same metric slices, so those use the default cache
     // policy (the second read hits).  The LDS copy of x is consumed when the registers are filled, so the same LDS serves as
     // the accumulator y (2 x max_loc doubles per batch); the boundary-face term re-reads its few x values from global memory.
-    template <int NB, int NQS, int NQM>
+    // NATIVE: x and y in the plan's own vector ordering (pairs (u, v), a batch's owned dofs contiguous; see helm_lane_kernel): the
+    // 128 threads gather pairs with 16-byte loads at addresses known at kernel entry and write pairs back the same way -- no
+    // dof list and no destination list for owned dofs (irregular 121,856-quad mesh: n_basis 6 145.6 -> 126.6 us, 7 163.1 -> 149.5 us).
+    // Measured and removed (profiles/r03/config5_ab.txt): the batch's mass weights copied into LDS through the DMA path
+    // (global_load_lds_dwordx4, no destination registers, both wavefronts sharing the copy; NQM dependent round trips fewer) --
+    // 10-18 % SLOWER at n_basis 6-8 (native ordering, same mesh: n_basis 6 126.6 -> 139.8 us, 7 149.5 -> 168.9 us): a
+    // wavefront's LDS-DMA pieces are served one at a time, and the LDS they need costs a quarter of the resident workgroups.
+    template <int NB, int NQS, int NQM, bool NATIVE = false>
     __global__ void __launch_bounds__(128, (NB <= 6 ? 4 : 3)) helm_mfma_kernel(HelmArgs A, const double *__restrict__ PS, const double *__restrict__ DS,
                                                               const double *__restrict__ PM, const double *__restrict__ PF,
                                                               const double *__restrict__ Gm, long long gm_stride,
                                                               const double *__restrict__ Am, long long am_stride)
     {
-        static_assert(NB >= 6 && NB <= 8 && NQS <= 16 && NQM <= 16, "xi-indices k = g + 4 s with s < 2");
+        static_assert(NB >= 5 && NB <= 8 && NQS <= 16 && NQM <= 16, "xi-indices k = g + 4 s with s < 2");
         constexpr int NN = NB * NB, NP = (NN + 1) / 2, PEM = 16;
         constexpr int JS = (NQS + 3) / 4, JM = (NQM + 3) / 4;
         // stiffness / mass slices per dependent round trip.  Same-box A/B of four builds (profiles/r02/mfma_grouping_ab.txt): at
@@ -2025,6 +2125,47 @@ namespace
             }
 
         constexpr int ROWS = 7; // 128 threads x 7 = 896 dofs per pass: a 4x4-element batch of n_basis 8 (841) in one
+        int own0 = 0, nown = 0;
+        const int *bp = nullptr, *bs = nullptr;
+        const int bcap = A.bstride - 1;
+        const dbl2_t *X2 = reinterpret_cast<const dbl2_t *>(A.x);
+        if constexpr (NATIVE)
+        {
+            own0 = A.own_off[patch];
+            nown = A.own_off[patch + 1] - own0;
+            bp = A.bpos + (size_t)patch * A.bstride;
+            bs = A.bslot + (size_t)patch * A.bstride;
+            for (int base = 0; base < nloc; base += 128 * ROWS)
+            {
+                int pos[ROWS];
+#pragma unroll
+                for (int j = 0; j < ROWS; ++j)
+                {
+                    const int i = base + 128 * j + (int)threadIdx.x;
+                    pos[j] = own0 + i;
+                    if (base + 128 * j + 127 >= nown) // (workgroup-uniform) a row that holds border dofs
+                        pos[j] = bp[max(0, min(i - nown, bcap))];
+                }
+                dbl2_t xv2[ROWS];
+#pragma unroll
+                for (int j = 0; j < ROWS; ++j)
+                {
+                    const int i = base + 128 * j + (int)threadIdx.x;
+                    xv2[j] = X2[i < nown ? own0 + i : pos[j]];
+                }
+#pragma unroll
+                for (int j = 0; j < ROWS; ++j)
+                {
+                    const int i = base + 128 * j + (int)threadIdx.x;
+                    if (i < nloc)
+                    {
+                        xy[i] = xv2[j].x;
+                        xy[ML + i] = xv2[j].y;
+                    }
+                }
+            }
+        }
+        else
         for (int base = 0; base < nloc; base += 128 * ROWS)
         {
             int gi[ROWS];
@@ -2298,7 +2439,13 @@ namespace
                     for (int k = 0; k < NB; ++k)
                     {
                         fl[k] = fli[k];
-                        w[k] = xo[dofs[fl[k]]];
+                        if constexpr (NATIVE)
+                        {
+                            const dbl2_t t = X2[fl[k] < nown ? own0 + fl[k] : bp[fl[k] - nown]];
+                            w[k] = comp ? t.x : t.y; // the other component
+                        }
+                        else
+                            w[k] = xo[dofs[fl[k]]];
                     }
                     for (int q = 0; q < nqF; ++q)
                     {
@@ -2326,6 +2473,22 @@ namespace
         }
 
         // ------------------------------------------------------------ write out
+        if constexpr (NATIVE)
+        {
+            // both components of every local dof are in LDS: all 128 threads write pairs (the colour / face phases ended on a barrier)
+            dbl2_t *Y2 = reinterpret_cast<dbl2_t *>(A.y), *P2 = reinterpret_cast<dbl2_t *>(A.part);
+            for (int i = threadIdx.x; i < nloc; i += 128)
+            {
+                dbl2_t r;
+                r.x = xy[i];
+                r.y = xy[ML + i];
+                if (i < nown)
+                    Y2[own0 + i] = r;
+                else
+                    P2[bs[min(i - nown, bcap)]] = r;
+            }
+            return;
+        }
         const int *slot = A.slot_of + off;
         constexpr int WROWS = 14;
         for (int base = 0; base < nloc; base += 64 * WROWS)
@@ -2346,6 +2509,29 @@ namespace
                     A.part[2 * (size_t)(-dest[j] - 1) + cmp] = xy[cmp * ML + i]; // a slot is the pair (u, v); this wavefront holds one component
             }
         }
+    }
+
+    template <int NB, int NQS, int NQM>
+    void launch_helm_mfma(const cuddh_helmholtz_plan *p, const HelmArgs &A, hipStream_t st, bool native)
+    {
+        const dim3 grid(8 * A.xcd_chunk), block(128); // one wavefront per component
+        const size_t lds = (size_t)2 * p->max_loc * sizeof(double);
+        if (native)
+            hipLaunchKernelGGL((helm_mfma_kernel<NB, NQS, NQM, true>), grid, block, lds, st, A, p->PS, p->DS, p->PM, p->PF, p->Gm, p->gm_stride, p->Am, p->am_stride);
+        else
+            hipLaunchKernelGGL((helm_mfma_kernel<NB, NQS, NQM, false>), grid, block, lds, st, A, p->PS, p->DS, p->PM, p->PF, p->Gm, p->gm_stride, p->Am, p->am_stride);
+    }
+
+    void launch_helm_mfma_any(const cuddh_helmholtz_plan *p, const HelmArgs &A, hipStream_t st, bool native)
+    {
+        if (p->nb == 5)
+            launch_helm_mfma<5, 6, 9>(p, A, st, native);
+        else if (p->nb == 6)
+            launch_helm_mfma<6, 7, 11>(p, A, st, native);
+        else if (p->nb == 7)
+            launch_helm_mfma<7, 8, 12>(p, A, st, native);
+        else
+            launch_helm_mfma<8, 9, 14>(p, A, st, native);
     }
 
     __global__ void __launch_bounds__(256) op_border_kernel(int n_shared, int accumulate, const int *__restrict__ shared_dof,
@@ -2665,7 +2851,7 @@ extern "C"
         };
         // ---- plan-native vector ordering (lane-form plans): owned dofs patch by patch, then the border dofs in shared_dof order
         size_t native_list_entries = 0;
-        if (want_pairs && !mfma && pe == 64)
+        if (nqS > 0 && nqM > 0) // every fused plan; which kernels take native vectors: cuddh_hip_helmholtz_plan_has_native
         {
             std::vector<int> own_off(n_patches + 1, 0);
             for (int q = 0; q < n_patches; ++q)
@@ -2876,6 +3062,14 @@ extern "C"
         if (!supported(nb, nqS, nqM) || n_elem <= 0)
             return static_cast<int>(hipErrorNotSupported);
         int pe = helm_mfma(nb, nqS, nqM) ? 16 : PE;
+        // n_basis 5 sits between the two schemes: one element per lane needs more registers than 3 wavefronts per SIMD have
+        // (26 spilled), the matrix-core scheme pads 5 xi-indices to 8.  Measured (profiles/r03/config5_ab.txt, 768^2): one element
+        // per lane 385 us, matrix cores 479 us (reference ordering) / 425 us (native ordering) -- the default stays;
+        // CUDDH_HELM_NB5_MFMA=1 selects the matrix-core scheme (tests keep it correct)
+        if (nb == 5 && nqS == 6 && nqM == 9)
+            if (const char *e = std::getenv("CUDDH_HELM_NB5_MFMA"))
+                if (std::atoi(e) != 0)
+                    pe = 16;
         if (pe == PE && nb <= 4)
         {
             // Affine plans (uniform stiffness metric, read through scalar loads) use 64-element patches, two wavefronts sharing
@@ -3008,20 +3202,8 @@ extern "C"
         HelmArgs A = plan_args(p, x, y);
         A.omega = omega;
 
-        if (p->Gm && p->Am) // n_basis 6-8: fp64 matrix cores, one 16-element batch per workgroup
-        {
-            const size_t lds = (size_t)2 * p->max_loc * sizeof(double);
-            const dim3 grid(8 * A.xcd_chunk), block(128); // one wavefront per component
-            if (p->nb == 6)
-                hipLaunchKernelGGL((helm_mfma_kernel<6, 7, 11>), grid, block, lds, st, A, p->PS, p->DS, p->PM, p->PF, p->Gm, p->gm_stride, p->Am,
-                                   p->am_stride);
-            else if (p->nb == 7)
-                hipLaunchKernelGGL((helm_mfma_kernel<7, 8, 12>), grid, block, lds, st, A, p->PS, p->DS, p->PM, p->PF, p->Gm, p->gm_stride, p->Am,
-                                   p->am_stride);
-            else
-                hipLaunchKernelGGL((helm_mfma_kernel<8, 9, 14>), grid, block, lds, st, A, p->PS, p->DS, p->PM, p->PF, p->Gm, p->gm_stride, p->Am,
-                                   p->am_stride);
-        }
+        if (p->Gm && p->Am) // n_basis 6-8 (5 on request): fp64 matrix cores, one 16-element batch per workgroup
+            launch_helm_mfma_any(p, A, st, false);
         else if (p->nb == 4)
             launch_patch<4, 5, 8>(p, A, st);
         else if (p->nb == 3)
@@ -3043,7 +3225,12 @@ extern "C"
     }
 
     // ---- plan-native vector ordering (see cuddh_helmholtz_plan): for solvers that keep their vectors in the plan's order
-    int cuddh_hip_helmholtz_plan_has_native(const cuddh_helmholtz_plan *p) { return (p && p->own_off && p->lane_form && p->nb <= 4) ? 1 : 0; }
+    int cuddh_hip_helmholtz_plan_has_native(const cuddh_helmholtz_plan *p)
+    {
+        if (!p || !p->own_off)
+            return 0;
+        return 1; // every fused kernel takes native vectors: helm_lane_kernel, helm_patch_kernel, helm_mfma_kernel
+    }
 
     int cuddh_hip_helmholtz_to_native(const cuddh_helmholtz_plan *p, const double *x, double *z, void *stream)
     {
@@ -3072,10 +3259,14 @@ extern "C"
         hipStream_t st = as_stream(stream);
         HelmArgs A = plan_args(p, z_in, z_out);
         A.omega = omega;
-        if (p->nb == 4)
+        if (p->Gm && p->Am)
+            launch_helm_mfma_any(p, A, st, true);
+        else if (p->nb == 4)
             launch_patch<4, 5, 8>(p, A, st, true);
         else if (p->nb == 3)
             launch_patch<3, 4, 6>(p, A, st, true);
+        else if (p->nb == 5)
+            launch_patch<5, 6, 9>(p, A, st, true);
         else
             launch_patch<2, 3, 5>(p, A, st, true);
         int err = launch_status();

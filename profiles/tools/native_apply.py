@@ -1,5 +1,5 @@
 """Fused Helmholtz apply: reference ordering ([u; v], H1Space numbering) vs plan-native ordering (pairs, owned dofs of a patch
-contiguous), same plan, same box, alternating.  usage: native_apply.py [nx=1024] [nb=4] [reps=30] [refine=-1]"""
+contiguous), same plan, same box, alternating.  usage: native_apply.py [nx=1024] [nb=4] [reps=30] [refine=-1]     (environment: CUDDH_HELM_NB5_MFMA, CUDDH_HELM_LANE ... select the kernel)"""
 import math
 import os
 import sys

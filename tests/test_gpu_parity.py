@@ -492,18 +492,23 @@ def test_fused_helmholtz_apply(cuda, kind, nx, nb):
 
 @pytest.mark.parametrize("affine", ["0", "1"])
 @pytest.mark.parametrize("kind,nx", [("structured", 10), ("structured", 37), ("unstructured", 0), ("refined", 2)])
-@pytest.mark.parametrize("nb", [2, 3, 4])
-def test_fused_helmholtz_apply_native_ordering(cuda, monkeypatch, kind, nx, nb, affine):
-    """The lane form of the fused apply on vectors in the PLAN'S OWN ordering (pairs (u, v); a patch's owned dofs contiguous;
+@pytest.mark.parametrize("nb,variant", [(2, "lane"), (3, "lane"), (4, "lane"), (2, "patch"), (3, "patch"), (4, "patch"), (5, "patch"), (5, "mfma"), (6, "mfma"),
+                                        (7, "mfma"), (8, "mfma")])
+def test_fused_helmholtz_apply_native_ordering(cuda, monkeypatch, kind, nx, nb, variant, affine):
+    """The lane form (n_basis 2-4) and the matrix-core form (n_basis 5-8) of the fused apply on vectors in the PLAN'S OWN ordering (pairs (u, v); a patch's owned dofs contiguous;
     include/cuddh_hip.h: cuddh_hip_helmholtz_apply_native): against the oracle through the permutation, and bitwise against
     the reference-ordering apply (same arithmetic, same order per element and per dof); gmres() on the native vectors takes the
-    same iterations as on the reference ordering.  The lane form is forced (CUDDH_HELM_LANE=1: its size rule would pick
-    helm_patch_kernel for meshes this small); general-geometry layout and, on the uniform meshes, the affine form."""
+    same iterations as on the reference ordering.  Every fused kernel: helm_lane_kernel (forced with CUDDH_HELM_LANE=1: its size
+    rule would pick helm_patch_kernel for meshes this small), helm_patch_kernel (n_basis 2-5, 32- and 64-element patches),
+    helm_mfma_kernel (n_basis 6-8, and 5 on request); general-geometry layout and, on the uniform meshes, the affine form."""
     import torch
 
     import cuddhelmholtz_amd as cd
 
-    monkeypatch.setenv("CUDDH_HELM_LANE", "1")
+    if nb <= 4 and variant != "patch":
+        monkeypatch.setenv("CUDDH_HELM_LANE", "1")
+    if nb == 5 and variant != "patch":
+        monkeypatch.setenv("CUDDH_HELM_NB5_MFMA", "1")  # n_basis 5 in the matrix-core scheme (16-element batches)
     monkeypatch.setenv("CUDDH_PLAN_AFFINE", affine)
     if kind == "refined":
         xy, elems = load_unstructured_square()
@@ -522,12 +527,13 @@ def test_fused_helmholtz_apply_native_ordering(cuda, monkeypatch, kind, nx, nb, 
     ax = 0.5 + rng.random(ofs.size)
     omega = 7.0
     A = cd.HelmholtzOperator(omega, to_dev(torch, a2, cuda), to_dev(torch, ax, cuda), fem, fs)
-    assert A.fused()
-    if affine == "1" and kind == "structured" and nb > 2:
-        # affine plans of n_basis 3, 4 run helm_patch_kernel (two wavefronts per patch): reference ordering only
-        assert A.kernel().startswith(f"helm_patch_kernel<{nb},") and not A.has_native()
-        return
-    assert A.kernel().startswith(f"helm_lane_kernel<{nb},") and A.has_native()
+    assert A.fused() and A.has_native()
+    if affine == "1" and kind == "structured" and nb in (3, 4):
+        assert A.kernel().startswith(f"helm_patch_kernel<{nb},")  # affine plans of n_basis 3, 4: two wavefronts per 64-element patch
+    elif variant == "patch":
+        assert A.kernel().startswith(f"helm_patch_kernel<{nb},")
+    else:
+        assert A.kernel().startswith(f"helm_lane_kernel<{nb}," if nb <= 4 else f"helm_mfma_kernel<{nb},")
     xh = rng.standard_normal(2 * n)
     x = to_dev(torch, xh, cuda)
     z = torch.full((2 * n,), 7.0, dtype=torch.float64, device=cuda)
