@@ -2098,7 +2098,14 @@ namespace
         // n_basis 7 two / four per trip fit the 168 registers of 3 wavefronts per SIMD (161) and gain 6-8 % (irregular
         // 121,856-quad mesh 190 -> 179 us, 384^2 230 -> 214 us); n_basis 6 (128-register cap, 21 spilled; 3 wavefronts per SIMD
         // without spills: no better) and n_basis 8 (18 spilled) lose 5 %, four / six per trip at 2 wavefronts per SIMD loses 15 %
+        // (round 3, native ordering, same-box A/B of build variants at n_basis 6, profiles/r03/config5_ab.txt: 3 wavefronts per SIMD
+        // 126.5 -> 142 us, with two / four slices per trip 137 us, two mass slices per trip at 4 wavefronts 131 us, the element ->
+        // local dof map re-read before the colour phases instead of held in registers 128 us -- none kept)
         constexpr int GS = NB == 7 ? 2 : 1, GM = NB == 7 ? 4 : 1;
+        // forward products (rows = quadrature points) on v_mfma_f64_4x4x4 like the backward ones: JS row blocks x KB xi blocks
+        // instead of 16 padded rows per k-step (n_basis 6: 7 of 16 rows were real).  Same-box A/B: n_basis 6 +2 %, 7 +2 %;
+        // n_basis 8 (three row blocks, spills) -9 %, so it keeps the 16x16x4 form
+        constexpr bool FWD4 = NB <= 7;
         extern __shared__ double lds[];
         const int patch = (blockIdx.x & 7) * A.xcd_chunk + (blockIdx.x >> 3);
         if (patch >= A.n_patches)
@@ -2211,7 +2218,22 @@ namespace
         // ------------------------------------------------------------ stiffness slices
         {
             constexpr int KB = (NB + 3) / 4; // backward products on v_mfma_f64_4x4x4_f64, as in op_mfma_kernel
-            double AfD[2], AfP[2], AbD[KB][JS], AbP[KB][JS];
+            double AfD[FWD4 ? 1 : 2], AfP[FWD4 ? 1 : 2], AbD[KB][JS], AbP[KB][JS];
+            double AfD4[FWD4 ? JS : 1][KB], AfP4[FWD4 ? JS : 1][KB]; // A[i][k] <-> lane i + 4 b + 16 k: row q = 4 j + (lane & 3), column k = 4 s + g
+            if constexpr (FWD4)
+            {
+#pragma unroll
+                for (int j = 0; j < JS; ++j)
+#pragma unroll
+                    for (int s = 0; s < KB; ++s)
+                    {
+                        const int q = 4 * j + (lane & 3), kp = 4 * s + g;
+                        const bool ok = q < NQS && kp < NB;
+                        AfD4[j][s] = ok ? DS[q + NQS * kp] : 0.0;
+                        AfP4[j][s] = ok ? PS[q + NQS * kp] : 0.0;
+                    }
+            }
+            else
 #pragma unroll
             for (int s = 0; s < 2; ++s)
             {
@@ -2274,12 +2296,37 @@ namespace
                         pl[s] = a;
                         dl[s] = b;
                     }
-                    mfma_d4 dx = {0, 0, 0, 0}, dy = {0, 0, 0, 0};
-#pragma unroll
-                    for (int s = 0; s < 2; ++s)
+                    double dx[JS], dy[JS];
+                    if constexpr (FWD4)
                     {
-                        dx = __builtin_amdgcn_mfma_f64_16x16x4f64(AfD[s], pl[s], dx, 0, 0, 0);
-                        dy = __builtin_amdgcn_mfma_f64_16x16x4f64(AfP[s], dl[s], dy, 0, 0, 0);
+                        // forward products on the 4x4x4 form too: JS row blocks x KB xi blocks instead of 16 padded rows per k-step
+#pragma unroll
+                        for (int j = 0; j < JS; ++j)
+                        {
+                            dx[j] = dy[j] = 0.0;
+#pragma unroll
+                            for (int s = 0; s < KB; ++s)
+                            {
+                                dx[j] = __builtin_amdgcn_mfma_f64_4x4x4f64(AfD4[j][s], pl[s], dx[j], 0, 0, 0);
+                                dy[j] = __builtin_amdgcn_mfma_f64_4x4x4f64(AfP4[j][s], dl[s], dy[j], 0, 0, 0);
+                            }
+                        }
+                    }
+                    else
+                    {
+                        mfma_d4 dx4 = {0, 0, 0, 0}, dy4 = {0, 0, 0, 0};
+#pragma unroll
+                        for (int s = 0; s < 2; ++s)
+                        {
+                            dx4 = __builtin_amdgcn_mfma_f64_16x16x4f64(AfD[s], pl[s], dx4, 0, 0, 0);
+                            dy4 = __builtin_amdgcn_mfma_f64_16x16x4f64(AfP[s], dl[s], dy4, 0, 0, 0);
+                        }
+#pragma unroll
+                        for (int j = 0; j < JS; ++j)
+                        {
+                            dx[j] = dx4[j];
+                            dy[j] = dy4[j];
+                        }
                     }
                     double W0[KB], W1[KB];
 #pragma unroll
@@ -2311,7 +2358,20 @@ namespace
         {
             const double w2 = -A.omega * A.omega;
             constexpr int KB = (NB + 3) / 4;
-            double AfP[2], AbP[KB][JM];
+            double AfP[FWD4 ? 1 : 2], AbP[KB][JM];
+            double AfP4[FWD4 ? JM : 1][KB];
+            if constexpr (FWD4)
+            {
+#pragma unroll
+                for (int j = 0; j < JM; ++j)
+#pragma unroll
+                    for (int s = 0; s < KB; ++s)
+                    {
+                        const int q = 4 * j + (lane & 3), kp = 4 * s + g;
+                        AfP4[j][s] = (q < NQM && kp < NB) ? PM[q + NQM * kp] : 0.0;
+                    }
+            }
+            else
 #pragma unroll
             for (int s = 0; s < 2; ++s)
             {
@@ -2363,10 +2423,28 @@ namespace
                             a += PM[r + NQM * l] * U[c][s][l];
                         pl[s] = a;
                     }
-                    mfma_d4 v = {0, 0, 0, 0};
+                    double v[JM];
+                    if constexpr (FWD4)
+                    {
 #pragma unroll
-                    for (int s = 0; s < 2; ++s)
-                        v = __builtin_amdgcn_mfma_f64_16x16x4f64(AfP[s], pl[s], v, 0, 0, 0);
+                        for (int j = 0; j < JM; ++j)
+                        {
+                            v[j] = 0.0;
+#pragma unroll
+                            for (int s = 0; s < KB; ++s)
+                                v[j] = __builtin_amdgcn_mfma_f64_4x4x4f64(AfP4[j][s], pl[s], v[j], 0, 0, 0);
+                        }
+                    }
+                    else
+                    {
+                        mfma_d4 v4 = {0, 0, 0, 0};
+#pragma unroll
+                        for (int s = 0; s < 2; ++s)
+                            v4 = __builtin_amdgcn_mfma_f64_16x16x4f64(AfP[s], pl[s], v4, 0, 0, 0);
+#pragma unroll
+                        for (int j = 0; j < JM; ++j)
+                            v[j] = v4[j];
+                    }
                     double W[KB];
 #pragma unroll
                     for (int rb = 0; rb < KB; ++rb)
