@@ -559,46 +559,78 @@ class ShardedHelmholtz:
         self.op = cd.HelmholtzOperator(omega, dev(a2x[p.l2g]), dev(ax[p.face_l2g]), p.fem, p.fs)
         self.n_loc = p.n_loc
         idx = lambda ids: torch.from_numpy(p.both_components(ids)).to(self.device)  # noqa: E731
-        self.own_to = {s: idx(v) for s, v in p.own_to.items()}
-        self.halo_from = {s: idx(v) for s, v in p.halo_from.items()}
         self.halo_idx = idx(p.halo)
         self.owned_idx = idx(p.owned)
-        # one gather / scatter launch per exchange whatever the number of neighbours: concatenated index lists, per-neighbour
-        # messages are views into one buffer
-        cat = lambda d: (torch.cat([d[s] for s in sorted(d)]) if d else torch.zeros(0, dtype=torch.long, device=self.device))  # noqa: E731
-        self._own_cat, self._halo_cat = cat(self.own_to), cat(self.halo_from)
-        self._own_split = [(s, self.own_to[s].numel()) for s in sorted(self.own_to)]
-        self._halo_split = [(s, self.halo_from[s].numel()) for s in sorted(self.halo_from)]
+        # One pack / unpack launch per exchange whatever the number of neighbours (cuddh_hip_halo_pack_f64 / _unpack_f64: the HIP
+        # kernels the C++ host uses, include/cuddh_hip.h): concatenated local-dof lists, peers in increasing rank; a dof travels as
+        # the pair (u, v), so a neighbour's message is a contiguous piece of the one buffer.
+        def cat(d):
+            ids = np.concatenate([d[s] for s in sorted(d)]) if d else np.zeros(0, dtype=np.int64)
+            return torch.from_numpy(ids.astype(np.int32)).to(self.device), [(s, int(d[s].size)) for s in sorted(d)]
+
+        self._own_ids, self._own_split = cat(p.own_to)
+        self._halo_ids, self._halo_split = cat(p.halo_from)
+
+        def views(ids, split):  # {peer: its piece of the concatenated list} (local dof ids)
+            out, o = {}, 0
+            for s, k in split:
+                out[s] = ids[o:o + k]
+                o += k
+            return out
+
+        self.own_to, self.halo_from = views(self._own_ids, self._own_split), views(self._halo_ids, self._halo_split)
         self._scratch = torch.zeros(2 * p.n_loc, dtype=torch.float64, device=self.device)
 
     # ---- the two exchanges, as pack / unpack pairs (an in-process replay of several ranks calls them directly)
-    @staticmethod
-    def _views(buf, split):
-        out, o = {}, 0
-        for s, n in split:
-            out[s] = buf[o:o + n]
-            o += n
-        return out
+    def _stream(self):
+        import ctypes as C
 
-    def _joined(self, received, split):
         import torch
 
-        return torch.cat([received[s].to(self.device) for s, _ in split]) if split else None
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _pack(self, v, ids, split, clear: bool):
+        """{peer: its piece of the packed buffer} of the entries `ids` of the local vector v (pairs (u, v)); clear: zero them in v"""
+        import ctypes as C
+
+        import torch
+
+        from . import _native as N
+
+        n = int(ids.numel())
+        buf = torch.empty(2 * n, dtype=torch.float64, device=self.device)
+        if n:
+            N.check(N.lib.cuddh_hip_halo_pack_f64(n, self.n_loc, C.c_void_p(ids.data_ptr()), C.c_void_p(v.data_ptr()), C.c_void_p(buf.data_ptr()),
+                                                   1 if clear else 0, self._stream()))
+        out, o = {}, 0
+        for s, k in split:
+            out[s] = buf[2 * o:2 * (o + k)]
+            o += k
+        return out
+
+    def _unpack(self, v, ids, split, received, add: bool) -> None:
+        import ctypes as C
+
+        from . import _native as N
+
+        o = 0
+        for s, k in split:  # one launch per sender, in rank order: partial sums reach a dof in a fixed order
+            piece = received[s].to(self.device).contiguous()
+            N.check(N.lib.cuddh_hip_halo_unpack_f64(k, self.n_loc, C.c_void_p(ids.data_ptr() + 4 * o), C.c_void_p(piece.data_ptr()),
+                                                     C.c_void_p(v.data_ptr()), 1 if add else 0, self._stream()))
+            o += k
 
     def pack_x(self, x):
-        return self._views(x.index_select(0, self._own_cat), self._own_split)
+        return self._pack(x, self._own_ids, self._own_split, False)
 
     def unpack_x(self, x, received) -> None:
-        if self._halo_split:
-            x.index_copy_(0, self._halo_cat, self._joined(received, self._halo_split))
+        self._unpack(x, self._halo_ids, self._halo_split, received, False)
 
     def pack_y(self, y):
-        return self._views(y.index_select(0, self._halo_cat), self._halo_split)
+        return self._pack(y, self._halo_ids, self._halo_split, True)  # the halo entries of y are handed to their owners and cleared
 
     def unpack_y(self, y, received) -> None:
-        if self._own_split:
-            y.index_add_(0, self._own_cat, self._joined(received, self._own_split))
-        y.index_fill_(0, self.halo_idx, 0.0)
+        self._unpack(y, self._own_ids, self._own_split, received, True)
 
     def _exchange(self, outgoing, incoming_split):
         import torch
@@ -607,8 +639,11 @@ class ShardedHelmholtz:
         stage = (lambda t: t.cpu()) if self.host_staging else (lambda t: t)  # noqa: E731
         sbuf = {s: stage(t.contiguous()) for s, t in outgoing.items()}
         total = sum(n for _, n in incoming_split)
-        rall = torch.empty(total, dtype=torch.float64, device="cpu" if self.host_staging else self.device)
-        rbuf = self._views(rall, incoming_split)
+        rall = torch.empty(2 * total, dtype=torch.float64, device="cpu" if self.host_staging else self.device)
+        rbuf, o = {}, 0
+        for s, k in incoming_split:
+            rbuf[s] = rall[2 * o:2 * (o + k)]
+            o += k
         ops = []
         for s in sorted(set(sbuf) | set(rbuf)):
             if s in sbuf:

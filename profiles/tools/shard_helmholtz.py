@@ -46,17 +46,17 @@ def local_step():
     xs = A._scratch
     xs.copy_(x)
     out = A.pack_x(xs)                                     # what would be sent to the halo holders
-    A.unpack_x(xs, {s: torch.zeros(i.numel(), dtype=torch.float64, device=dev) for s, i in A.halo_from.items()})
+    A.unpack_x(xs, {s: torch.zeros(2 * i.numel(), dtype=torch.float64, device=dev) for s, i in A.halo_from.items()})
     A.op.action(xs, y)
     back = A.pack_y(y)                                     # partial sums for the owners
-    A.unpack_y(y, {s: torch.zeros(i.numel(), dtype=torch.float64, device=dev) for s, i in A.own_to.items()})
+    A.unpack_y(y, {s: torch.zeros(2 * i.numel(), dtype=torch.float64, device=dev) for s, i in A.own_to.items()})
     return out, back
 
 
 t_all = timeit(local_step)
 t_op = timeit(lambda: A.op.action(x, y))
-sx = sum(i.numel() for i in A.own_to.values()) * 8
-sy = sum(i.numel() for i in A.halo_from.values()) * 8
+sx = sum(i.numel() for i in A.own_to.values()) * 16
+sy = sum(i.numel() for i in A.halo_from.values()) * 16
 print(f"nx={nx} rank {rank}/{world}: {len(p.my_elems)} elements, {p.n_loc} local dofs ({p.owned.size} owned, {p.halo.size} halo), "
       f"neighbours x:{sorted(A.own_to)} y:{sorted(A.halo_from)}, messages {sx / 1024:.0f} KiB out (x) + {sy / 1024:.0f} KiB out (y); "
       f"set-up {t_setup:.1f} s; local fused apply {t_op * 1e6:.1f} us; with scratch copy, pack and unpack {t_all * 1e6:.1f} us")
