@@ -158,6 +158,9 @@ namespace
     // 18.0 us, 512^2 unchanged; at n_basis 5 it spills 35 registers at 3 wavefronts per SIMD: 421 -> 549 us, not used there.  A
     // double-buffered chain at 2 wavefronts per SIMD for n_basis 5 -- next slice requested before the current one is computed
     // -- compiled to 256 registers + 13 spilled with the requests sunk below the arithmetic again: 431 -> 450 us, removed)
+#ifndef HELM_PATCH_RELOAD_MAP
+#define HELM_PATCH_RELOAD_MAP 1
+#endif
     // NATIVE: x and y in the plan's own vector ordering (pairs (u, v), a patch's owned dofs contiguous; see helm_lane_kernel)
     template <int NB, int NQS, int NQM, bool NT, bool UG, int PEK, int MODE = 0, bool NATIVE = false>
     __global__ void __launch_bounds__(2 * PEK, (NB >= 5 ? (UG ? 2 : 3) : ((NB == 4 && !UG) ? 3 : 4))) helm_patch_kernel(HelmArgs A, const double *__restrict__ PS, const double *__restrict__ DS,
@@ -505,6 +508,17 @@ namespace
         }
 
         // accumulate: elements of one colour touch disjoint dofs
+        if constexpr (NB == 5 && !UG && HELM_PATCH_RELOAD_MAP)
+        {
+            // n_basis 5 at 3 wavefronts per SIMD: the element -> local dof map (13 registers) is not used between the register fill
+            // and here, and the compiler spills it across the slices (a scratch store and a scratch load per register and lane).
+            // Re-reading it (cache-hot, 1.6 KB per patch) costs one load instead.
+            const uint32_t *li2 = li;
+            asm volatile("" : "+v"(li2)); // (opaque: a new load, not the values from kernel entry)
+#pragma unroll
+            for (int j = 0; j < NP; ++j)
+                lpk[j] = li2[j * PEK];
+        }
         {
             const double sgn = comp ? -1.0 : 1.0; // the v row is negated (symmetrised system)
             double *yc = yw + comp * ML;
