@@ -1,7 +1,7 @@
 #!/bin/bash
 # The driver's N = 1 bench line and the rocprofv3 --kernel-trace --stats summary of the same command (profiles/rNN/).
 # usage: bench_profile.sh TAG      -> gpurun_out/bench_TAG.json, gpurun_out/bench_TAG_kernel_stats.csv
-TAG=${1:-r02}
+TAG=${1:-r03}
 cd /tmp 2>/dev/null && export TMPDIR=/tmp && cd - >/dev/null
 python3 bench.py --steps 8 --warmup 2 > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err || { tail -5 gpurun_out/bench_$TAG.err; exit 1; }
 rm -rf gpurun_out/prof_$TAG
@@ -14,6 +14,6 @@ import json
 d = json.load(open("gpurun_out/bench_$TAG.json"))
 print({k: d[k] for k in ("value", "ms_per_step", "n_gpus")}, d["gmres_call"]["value"], d["config"]["setup_seconds"])
 r = d["roofline"]
-print(r["kernel"], r["achieved"], r["frac"], r["traffic"], r["measured_streams"])
+print(r["kernel"], r["achieved"], r["frac"], r["traffic"], r["measured_streams"], r.get("reference_ordering"))
 print({k: (v["achieved"], v["kernel"]) for k, v in r["single_operators"].items()})
 PY
