@@ -763,9 +763,16 @@ namespace
         constexpr bool TWO_AHEAD = !UG && !PRE && NB >= 4;
         constexpr bool EARLY_DEST = PRE || NB >= 4;
         double g_first[3 * NQS], g_second[3 * NQS];
-        if constexpr (!UG && !PRE)
+        // NATIVE (n_basis 4): the x values are requested FIRST and the slices behind them (native_gather below): loads return in
+        // order, and with the addresses of the owned dofs known at kernel entry nothing has to arrive before x is asked for -- the
+        // LDS copy of x is complete when 10 KB have arrived, not 28 (profiles/r03/lane_stamps_native.txt: 10 of a wavefront's 31 us
+        // passed before that), and the slices land while the registers are being filled
+        // (same-box A/B, profiles/r03/native_gather_ab.txt: structured 1024^2 within 1 % of the slices-first order -- the kernel moves
+        // its bytes at the rate the memory system gives 2,048 resident wavefronts either way -- irregular 487k-quad mesh 143 -> 140 us)
+        constexpr bool X_FIRST = NATIVE && !UG && !PRE && NB >= 4;
+        if constexpr (!UG && !PRE && !X_FIRST)
             load_stiff(0, g_first);
-        if constexpr (TWO_AHEAD)
+        if constexpr (TWO_AHEAD && !X_FIRST)
             load_stiff(1, g_second);
         // PRE: the whole metric block of the patch, requested in this order: dof indices (above), stiffness metric, x values
         // of the first gather pass, mass weights -- so that what the chain needs first is oldest (loads return in order)
@@ -798,38 +805,61 @@ namespace
             for (int j = 0; j < ROWS; ++j)
                 if (j >= j_own)
                     dest0[j] = slot[min(64 * j + lane, cap)];
-        if constexpr (NATIVE) // the slots of the border rows ride on the first round trip, like the native positions below
-#pragma unroll
-            for (int j = 0; j < ROWS; ++j)
-                if (j >= j_own)
-                    dest0[j] = bs[max(0, min(64 * j + lane - nown, bcap))];
         const dbl2_t *X2 = reinterpret_cast<const dbl2_t *>(A.x);
-        auto native_gather_pass = [&](int base)
+        // Native gather, written WITHOUT wave-uniform branches (a conditional load is a basic block of its own to the compiler, which
+        // then waits for every outstanding load at its end): the owned dofs are rows of 64 contiguous pairs at own0 + i (addresses
+        // clamped, writes predicated), the border dofs a short list of native positions handled on its own.
+        const int nbord = nloc - nown;
+        int bslot_early[2] = {0, 0}; // slots of the first 128 border dofs (an 8 x 8-element patch of n_basis 4 has 96-100), requested early
+        if constexpr (NATIVE)
         {
-            int pos[ROWS];
-#pragma unroll
-            for (int j = 0; j < ROWS; ++j)
+            bslot_early[0] = bs[min(lane, bcap)];
+            bslot_early[1] = bs[min(64 + lane, bcap)];
+        }
+        auto native_gather = [&]()
+        {
+            const int last = max(nown - 1, 0);
+            for (int base = 0; base == 0 || base < nown; base += 64 * ROWS)
             {
-                const int i = base + 64 * j + lane;
-                pos[j] = own0 + i; // rows of owned dofs: the address is known now
-                if (base + 64 * j + 63 >= nown)
-                    pos[j] = bp[max(0, min(i - nown, bcap))];
-            }
-            dbl2_t xv2[ROWS];
+                dbl2_t xv2[ROWS];
 #pragma unroll
-            for (int j = 0; j < ROWS; ++j)
-            {
-                const int i = base + 64 * j + lane;
-                xv2[j] = X2[i < nown ? own0 + i : pos[j]];
-            }
-#pragma unroll
-            for (int j = 0; j < ROWS; ++j)
-            {
-                const int i = base + 64 * j + lane;
-                if (i < nloc)
+                for (int j = 0; j < ROWS; ++j)
+                    xv2[j] = X2[own0 + min(base + 64 * j + lane, last)];
+                if (base == 0)
                 {
-                    xy[i] = xv2[j].x;
-                    xy[ML + i] = xv2[j].y;
+                    // the border dofs: native position from the list, then the value (a dependent pair of light round trips that
+                    // starts with the owned rows' requests already under way)
+                    for (int t0 = 0; t0 < nbord; t0 += 64)
+                    {
+                        const int t = t0 + lane;
+                        const dbl2_t xb = X2[bp[min(t, bcap)]];
+                        if (t < nbord)
+                        {
+                            xy[nown + t] = xb.x;
+                            xy[ML + nown + t] = xb.y;
+                        }
+                    }
+                    if constexpr (X_FIRST)
+                    {
+                        // behind the x requests: the first two stiffness slices
+                        asm volatile("" ::: "memory");
+                        __builtin_amdgcn_sched_barrier(0);
+                        load_stiff(0, g_first);
+                        if constexpr (TWO_AHEAD)
+                            load_stiff(1, g_second);
+                        asm volatile("" ::: "memory");
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < ROWS; ++j)
+                {
+                    const int i = base + 64 * j + lane;
+                    if (i < nown)
+                    {
+                        xy[i] = xv2[j].x;
+                        xy[ML + i] = xv2[j].y;
+                    }
                 }
             }
         };
@@ -883,10 +913,7 @@ namespace
             }
         };
         if constexpr (NATIVE)
-        {
-            for (int base = 0; base == 0 || base < nloc; base += 64 * ROWS)
-                native_gather_pass(base);
-        }
+            native_gather();
         else
         {
             gather_pass(0, std::true_type{});
@@ -1189,21 +1216,31 @@ namespace
         if constexpr (NATIVE)
         {
             dbl2_t *Y2 = reinterpret_cast<dbl2_t *>(A.y), *P2 = reinterpret_cast<dbl2_t *>(A.part);
-            for (int base = 0; base < nloc; base += 64 * ROWS)
+            for (int t0 = 0; t0 < nbord; t0 += 64) // border dofs to their slots
+            {
+                const int t = t0 + lane;
+                const int sl = t0 == 0 ? bslot_early[0] : (t0 == 64 ? bslot_early[1] : bs[min(t, bcap)]);
+                if (t < nbord)
+                {
+                    dbl2_t r;
+                    r.x = xy[nown + t];
+                    r.y = xy[ML + nown + t];
+                    P2[sl] = r;
+                }
+            }
+            for (int base = 0; base < nown; base += 64 * ROWS)
             {
 #pragma unroll
                 for (int j = 0; j < ROWS; ++j)
                 {
                     const int i = base + 64 * j + lane;
-                    if (i >= nloc)
-                        continue;
-                    dbl2_t r;
-                    r.x = xy[i];
-                    r.y = xy[ML + i];
                     if (i < nown)
+                    {
+                        dbl2_t r;
+                        r.x = xy[i];
+                        r.y = xy[ML + i];
                         Y2[own0 + i] = r; // 16 bytes per lane, 1 KiB contiguous per instruction
-                    else
-                        P2[base == 0 ? dest0[j] : bs[min(i - nown, bcap)]] = r;
+                    }
                 }
             }
             stamp(6);
