@@ -1,6 +1,8 @@
 // Native C++ driver for the global Helmholtz operator (BASELINE config 2 shape): unpreconditioned restarted GMRES on the
 // fused complex Helmholtz apply, written against csrc/include/cuddh.hpp.
-//   helmholtz_solve [nx=256] [n_basis=4] [omega_over_pi=8] [gmres_m=20] [maxit=10] [tol=1e-6] [out_dir=-]
+//   helmholtz_solve [nx=256] [n_basis=4] [omega_over_pi=8] [gmres_m=20] [maxit=10] [tol=1e-6] [out_dir=-] [ordering=native|reference]
+// ordering native (default): HelmholtzOperator::gmres -- the iteration vectors live in the plan's own ordering (permuted once at
+// entry and exit); reference: gmres() on [u; v] in H1Space numbering, the call the reference's examples make.
 // a(x) = 0.2 inside the disk of radius 1/4, 1 elsewhere (interpolated at the nodes; a = 1 on the boundary), two Gaussian
 // sources as in the reference's examples.  Prints one summary line; writes <out_dir>/xy.0000 and helmholtz.0000 unless "-".
 #include <chrono>
@@ -22,6 +24,7 @@ int main(int argc, char **argv)
     const int maxit = argc > 5 ? std::atoi(argv[5]) : 10;
     const double tol = argc > 6 ? std::atof(argv[6]) : 1e-6;
     const std::string out_dir = argc > 7 ? argv[7] : "-";
+    const bool native = !(argc > 8 && std::string(argv[8]) == "reference");
 
     Mesh2D mesh = Mesh2D::uniform_rect(nx, -1.0, 1.0, nx, -1.0, 1.0);
     Basis basis(nb);
@@ -58,7 +61,7 @@ int main(int argc, char **argv)
     using clk = std::chrono::steady_clock;
     detail::check_hip(cuddh_hip_stream_sync(stream()), "sync");
     const auto t0 = clk::now();
-    solver_out out = gmres(N, d_U, &A, d_b, m, maxit, tol, 0);
+    solver_out out = native ? A.gmres(d_U, d_b, m, maxit, tol, 0) : gmres(N, d_U, &A, d_b, m, maxit, tol, 0);
     detail::check_hip(cuddh_hip_stream_sync(stream()), "sync");
     const double t_gmres = std::chrono::duration<double>(clk::now() - t0).count();
 
@@ -72,6 +75,7 @@ int main(int argc, char **argv)
     for (int i = 0; i < N; ++i)
         unorm += h_U[i] * h_U[i];
     std::cout << "helmholtz_solve nx=" << nx << " nb=" << nb << " omega/pi=" << omega / M_PI << " N=" << N << " fused=" << A.fused()
+              << " ordering=" << ((native && A.has_native()) ? "native" : "reference")
               << " success=" << out.success << " num_iter=" << out.num_iter << " num_matvec=" << out.num_matvec
               << " rel_res=" << out.res_norm.back() / out.res_norm.front() << " |U|=" << std::sqrt(unorm) << " t_gmres=" << t_gmres
               << " DoF*iter/s=" << static_cast<double>(N) * out.num_matvec / t_gmres

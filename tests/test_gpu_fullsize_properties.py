@@ -202,6 +202,16 @@ def test_fused_helmholtz_linearity_symmetry_determinism_at_full_size(cuda, big, 
     assert Q.kernel() == "helm_lane_kernel<4,5,8,NT=1,UG=0,PRE=1> pe=64"
     Q.action(x, Bx)
     assert torch.equal(Bx, Ax)
+    # the same plan on vectors in its OWN ordering (pairs, a patch's owned dofs contiguous: what bench.py's roofline figure runs
+    # and HelmholtzOperator::gmres iterates on): a permutation in, the same numbers bit for bit out, fewer bytes as laid out
+    monkeypatch.delenv("CUDDH_HELM_PRE")
+    assert A.has_native()
+    zx, zy = torch.empty_like(x), torch.empty_like(x)
+    A.to_native(x, zx)
+    A.action_native(zx, zy)
+    A.from_native(zy, Bx)
+    assert torch.equal(Bx, Ax)
+    assert A.bytes_native() < A.bytes_per_apply(True) and A.bytes_native() < 1.04 * A.bytes_per_apply()
 
 
 def test_ddh_properties_at_full_size(cuda, big):
