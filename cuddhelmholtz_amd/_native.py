@@ -90,6 +90,13 @@ _sig("cuddh_hip_stream_sync", ci, vp)
 _sig("cuddh_hip_device_sync", ci)
 _sig("cuddh_hip_device_count", ci)
 _sig("cuddh_hip_current_device", ci)
+_sig("cuddh_hip_host_alloc", ci, C.POINTER(vp), cs)
+_sig("cuddh_hip_host_free", ci, vp)
+_sig("cuddh_hip_copy_d2h_async", ci, vp, vp, cs, vp)
+_sig("cuddh_hip_event_create", ci, C.POINTER(vp))
+_sig("cuddh_hip_event_record", ci, vp, vp)
+_sig("cuddh_hip_event_sync", ci, vp)
+_sig("cuddh_hip_event_destroy", ci, vp)
 _sig("cuddh_hip_error_string", cp, ci)
 _sig("cuddh_hip_reduce_ws_bytes", cs)
 _sig("cuddh_hip_axpby_f64", ci, ci, cd, vp, cd, vp, vp)

@@ -17,7 +17,7 @@ struct cuddh_helmholtz_plan;
 
 namespace cuddh
 {
-    class HelmholtzOperator : public Operator
+    class HelmholtzOperator : public Operator, public QueuesDeviceWorkOnly
     {
     public:
         /// a2x: DEVICE H1 nodal values of a^2(x); ax: DEVICE FaceSpace values of a(x)

@@ -18,6 +18,16 @@ namespace cuddh
         virtual void action(const double *in, double *out) const = 0;                 ///< out = A in (overwrites)
     };
 
+    /// Marker (not in the reference): an operator whose action() only queues work on cuddh::stream() -- no host-visible side effect,
+    /// no synchronisation the caller could observe.  gmres() may then queue the NEXT Arnoldi step's action() before it has looked at
+    /// the current step's Hessenberg column (one product may be computed and discarded when the iteration stops).  The library's
+    /// own device operators carry it; user operators (callbacks, operators that count their calls) do not and are driven strictly
+    /// in the reference's order.
+    struct QueuesDeviceWorkOnly
+    {
+        virtual ~QueuesDeviceWorkOnly() = default;
+    };
+
     /// fp32 operator: DDH acts on float trace vectors (reference include/DDH.hpp:22)
     class SinglePrecisionOperator
     {

@@ -45,7 +45,7 @@ namespace cuddh
     } // namespace detail
 
     /// (grad u, grad phi)
-    class StiffnessMatrix : public Operator
+    class StiffnessMatrix : public Operator, public QueuesDeviceWorkOnly
     {
     public:
         /// Gauss-Legendre rule with n_basis + 1 points
@@ -75,7 +75,7 @@ namespace cuddh
     };
 
     /// (a u, phi)
-    class MassMatrix : public Operator
+    class MassMatrix : public Operator, public QueuesDeviceWorkOnly
     {
     public:
         /// a == 1; Gauss-Legendre rule with n_basis + 1 points

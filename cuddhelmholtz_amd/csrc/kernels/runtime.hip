@@ -80,6 +80,23 @@ extern "C"
         return n;
     }
 
+    int cuddh_hip_host_alloc(void **ptr, size_t bytes) { return static_cast<int>(hipHostMalloc(ptr, bytes ? bytes : 1, hipHostMallocDefault)); }
+    int cuddh_hip_host_free(void *ptr) { return ptr ? static_cast<int>(hipHostFree(ptr)) : 0; }
+    int cuddh_hip_copy_d2h_async(void *h_dst, const void *src, size_t bytes, void *stream)
+    {
+        return bytes ? static_cast<int>(hipMemcpyAsync(h_dst, src, bytes, hipMemcpyDeviceToHost, cuddh_k::as_stream(stream))) : 0;
+    }
+    int cuddh_hip_event_create(void **ev)
+    {
+        hipEvent_t e = nullptr;
+        const hipError_t r = hipEventCreateWithFlags(&e, hipEventDisableTiming);
+        *ev = e;
+        return static_cast<int>(r);
+    }
+    int cuddh_hip_event_record(void *ev, void *stream) { return static_cast<int>(hipEventRecord(static_cast<hipEvent_t>(ev), cuddh_k::as_stream(stream))); }
+    int cuddh_hip_event_sync(void *ev) { return static_cast<int>(hipEventSynchronize(static_cast<hipEvent_t>(ev))); }
+    int cuddh_hip_event_destroy(void *ev) { return ev ? static_cast<int>(hipEventDestroy(static_cast<hipEvent_t>(ev))) : 0; }
+
     int cuddh_hip_current_device(void)
     {
         int d = 0;

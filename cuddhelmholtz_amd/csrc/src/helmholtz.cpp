@@ -116,7 +116,7 @@ namespace cuddh
 
     namespace
     {
-        class NativeView : public Operator
+        class NativeView : public Operator, public QueuesDeviceWorkOnly
         {
         public:
             explicit NativeView(const HelmholtzOperator &A_) : A(A_) {}

@@ -100,6 +100,31 @@ namespace cuddh
                 ~Guard() { cuddh_hip_free(p); }
             } guard{ws};
 
+            // Operators that only queue device work (operator.hpp: QueuesDeviceWorkOnly) are driven one Arnoldi step ahead of the host:
+            // two pinned Hessenberg columns and two events
+            const bool ahead = !red && dynamic_cast<const QueuesDeviceWorkOnly *>(A) != nullptr;
+            struct AheadBuffers
+            {
+                scalar *pin[2] = {nullptr, nullptr};
+                void *ev[2] = {nullptr, nullptr};
+                ~AheadBuffers()
+                {
+                    for (int i = 0; i < 2; ++i)
+                    {
+                        (void)cuddh_hip_host_free(pin[i]);
+                        (void)cuddh_hip_event_destroy(ev[i]);
+                    }
+                }
+            } ab;
+            if (ahead)
+                for (int i = 0; i < 2; ++i)
+                {
+                    detail::check_hip(cuddh_hip_host_alloc(reinterpret_cast<void **>(&ab.pin[i]), sizeof(scalar) * (m1 + 1)), "gmres pinned column");
+                    detail::check_hip(cuddh_hip_event_create(&ab.ev[i]), "gmres event");
+                }
+            scalar *const *pin = ab.pin;
+            void *const *ev = ab.ev;
+
             // 2-norm; with partitioned vectors the sum of squares is reduced over the ranks first
             auto norm_of = [&](const scalar *v) -> scalar
             {
@@ -152,22 +177,46 @@ namespace cuddh
                 std::fill(eta.begin(), eta.end(), zero);
                 eta[0] = r_nrm;
 
+                // One Arnoldi step queued on the stream: w = A v_k, modified Gram-Schmidt against v_0..v_k as a chain of fused stages
+                // (stage j applies the projection on v_{j-1} and leaves the partial sums of <w, v_j> -- the last one <w, w> -- for
+                // the next stage, so one launch per basis vector does what dot + reduce + axpy did; coefficients stay on the device),
+                // normalisation.  On breakdown (norm == 0) v_{k+1} becomes non-finite but is never used.
+                auto queue_step = [&](int k)
+                {
+                    scalar *vk = V + static_cast<std::size_t>(k) * n;
+                    scalar *vk1 = vk + n;
+                    A->action(vk, vk1);
+                    scalar *pa = static_cast<scalar *>(ws), *pb = pa + cuddh_hip_reduce_ws_bytes() / (2 * sizeof(double));
+                    detail::check_hip(k_mgs_stage(n, vk1, static_cast<const scalar *>(nullptr), V, pa, pa, dcol), "gmres mgs");
+                    for (int j = 0; j <= k; ++j)
+                    {
+                        const scalar *vj = V + static_cast<std::size_t>(j) * n;
+                        const scalar *vnext = (j < k) ? vj + n : nullptr;
+                        detail::check_hip(k_mgs_stage(n, vk1, vj, vnext, pa, pb, dcol + j), "gmres mgs");
+                        std::swap(pa, pb);
+                    }
+                    detail::check_hip(k_mgs_finish(n, vk1, pa, dcol + k + 1), "gmres normalise");
+                    if (ahead)
+                    {
+                        // the Hessenberg column leaves for pinned host memory behind the step; the next step may be queued behind it
+                        detail::check_hip(cuddh_hip_copy_d2h_async(pin[k & 1], dcol, sizeof(scalar) * (k + 2), stream()), "gmres column copy");
+                        detail::check_hip(cuddh_hip_event_record(ev[k & 1], stream()), "gmres event");
+                    }
+                };
+
                 int k1 = 0;
+                if (ahead)
+                    queue_step(0);
                 for (int k = 0; k < m; ++k)
                 {
                     k1 = k + 1;
                     scalar *vk = V + static_cast<std::size_t>(k) * n;
                     scalar *vk1 = vk + n;
+                    scalar *h = H.data() + static_cast<std::size_t>(m1) * k;
 
-                    A->action(vk, vk1);
-                    out.num_matvec++;
-
-                    // modified Gram-Schmidt against v0..vk as a chain of fused stages: stage j applies the projection
-                    // on v_{j-1} and leaves the partial sums of <w, v_j> (the last one <w, w>) for the next stage, so one
-                    // launch per basis vector does what dot + reduce + axpy did; coefficients stay on the device.
-                    // On breakdown (norm == 0) v_{k+1} becomes non-finite but is never used.
                     if (red)
                     {
+                        A->action(vk, vk1);
                         // partitioned vectors: every coefficient is summed over the ranks before it is applied
                         for (int j = 0; j < k1; ++j)
                         {
@@ -178,30 +227,29 @@ namespace cuddh
                         }
                         detail::check_hip(k_dot(n, vk1, vk1, dcol + k1, ws), "gmres dot");
                         red->fn(red->user, dcol + k1, 1, is_f64);
-                    }
-                    else
-                    {
-                        scalar *pa = static_cast<scalar *>(ws), *pb = pa + cuddh_hip_reduce_ws_bytes() / (2 * sizeof(double));
-                        detail::check_hip(k_mgs_stage(n, vk1, static_cast<const scalar *>(nullptr), V, pa, pa, dcol), "gmres mgs");
-                        for (int j = 0; j < k1; ++j)
-                        {
-                            const scalar *vj = V + static_cast<std::size_t>(j) * n;
-                            const scalar *vnext = (j + 1 < k1) ? vj + n : nullptr;
-                            detail::check_hip(k_mgs_stage(n, vk1, vj, vnext, pa, pb, dcol + j), "gmres mgs");
-                            std::swap(pa, pb);
-                        }
-                        detail::check_hip(k_mgs_finish(n, vk1, pa, dcol + k1), "gmres normalise");
-                    }
-
-                    scalar *h = H.data() + static_cast<std::size_t>(m1) * k;
-                    detail::check_hip(cuddh_hip_stream_sync(stream()), "gmres sync");
-                    detail::check_hip(cuddh_hip_copy_d2h_on(h, dcol, sizeof(scalar) * (k1 + 1), stream()), "gmres column copy");
-                    if (red)
-                    {
+                        detail::check_hip(cuddh_hip_stream_sync(stream()), "gmres sync");
+                        detail::check_hip(cuddh_hip_copy_d2h_on(h, dcol, sizeof(scalar) * (k1 + 1), stream()), "gmres column copy");
                         h[k1] = std::sqrt(h[k1]); // the reduced sum of squares
                         if (h[k1] != zero)
                             scal(n, one / h[k1], vk1);
                     }
+                    else if (ahead)
+                    {
+                        // one step ahead: step k + 1 is queued (its operator apply needs nothing from the host) before the host waits
+                        // for step k's column, so the device never idles while the host rotates; if the iteration stops at column k
+                        // the extra step is discarded (it wrote v_{k+2} and the device column, neither is read afterwards)
+                        if (k + 1 < m)
+                            queue_step(k + 1);
+                        detail::check_hip(cuddh_hip_event_sync(ev[k & 1]), "gmres event wait");
+                        std::copy(pin[k & 1], pin[k & 1] + k1 + 1, h);
+                    }
+                    else
+                    {
+                        queue_step(k);
+                        detail::check_hip(cuddh_hip_stream_sync(stream()), "gmres sync");
+                        detail::check_hip(cuddh_hip_copy_d2h_on(h, dcol, sizeof(scalar) * (k1 + 1), stream()), "gmres column copy");
+                    }
+                    out.num_matvec++;
 
                     if (h[k1] == zero)
                         break;

@@ -42,6 +42,16 @@ int cuddh_hip_stream_sync(void *stream);
 int cuddh_hip_device_sync(void);
 /* number of visible devices; 0 if there is no GPU (never fails) */
 int cuddh_hip_device_count(void);
+/* Pinned host memory, asynchronous device -> host copies and events: what the Arnoldi loop needs to fetch a Hessenberg column
+ * while the next matrix-vector product is already queued (csrc/src/krylov.cpp; the reference copies with blocking cudaMemcpy,
+ * source/linalg.cpp:67-83).  h_dst of copy_d2h_async must come from host_alloc. */
+int cuddh_hip_host_alloc(void **ptr, size_t bytes);
+int cuddh_hip_host_free(void *ptr);
+int cuddh_hip_copy_d2h_async(void *h_dst, const void *src, size_t bytes, void *stream);
+int cuddh_hip_event_create(void **ev);
+int cuddh_hip_event_record(void *ev, void *stream);
+int cuddh_hip_event_sync(void *ev);
+int cuddh_hip_event_destroy(void *ev);
 /* the calling thread's current device (hipGetDevice), -1 if there is none; the BLAS-1 wrappers key their reduction scratch by it */
 int cuddh_hip_current_device(void);
 const char *cuddh_hip_error_string(int err);
