@@ -413,7 +413,7 @@ namespace
             for (int l = 0; l < NB; ++l)
 #pragma unroll
                 for (int k = 0; k < NB; ++k)
-                    out[k + NB * l] += DS[q + NQS * k] * t0[l] + PS[q + NQS * k] * t1[l];
+                    out[k + NB * l] = fma(DS[q + NQS * k], t0[l], fma(PS[q + NQS * k], t1[l], out[k + NB * l]));
         };
 
         // mass: out(k,l) += -w^2 sum_q P(q,k) sum_r P(r,l) a(q,r) (sum_{k'l'} P(q,k') P(r,l') u(k',l'))
@@ -989,7 +989,7 @@ namespace
                 for (int l = 0; l < NB; ++l)
 #pragma unroll
                     for (int k = 0; k < NB; ++k)
-                        out[c][k + NB * l] += DS[q + NQS * k] * t0[l] + PS[q + NQS * k] * t1[l];
+                        out[c][k + NB * l] = fma(DS[q + NQS * k], t0[l], fma(PS[q + NQS * k], t1[l], out[c][k + NB * l]));
             }
         };
         const double w2 = -A.omega * A.omega;
@@ -1750,7 +1750,7 @@ namespace
                 for (int l = 0; l < NB; ++l)
 #pragma unroll
                     for (int k = 0; k < NB; ++k)
-                        out[k + NB * l] += D[q + NQ * k] * t0[l] + P[q + NQ * k] * t1[l];
+                        out[k + NB * l] = fma(D[q + NQ * k], t0[l], fma(P[q + NQ * k], t1[l], out[k + NB * l]));
             }
             else
             {
@@ -2022,7 +2022,7 @@ namespace
                 for (int s = 0; s < 2; ++s)
 #pragma unroll
                     for (int l = 0; l < NB; ++l)
-                        OUT[s][l] += P[r + NQ * l] * W0[s] + D[r + NQ * l] * W1[s];
+                        OUT[s][l] = fma(P[r + NQ * l], W0[s], fma(D[r + NQ * l], W1[s], OUT[s][l]));
             }
         }
         else
@@ -2136,8 +2136,8 @@ namespace
     // (global_load_lds_dwordx4, no destination registers, both wavefronts sharing the copy; NQM dependent round trips fewer) --
     // 10-18 % SLOWER at n_basis 6-8 (native ordering, same mesh: n_basis 6 126.6 -> 139.8 us, 7 149.5 -> 168.9 us): a
     // wavefront's LDS-DMA pieces are served one at a time, and the LDS they need costs a quarter of the resident workgroups.
-    template <int NB, int NQS, int NQM, bool NATIVE = false>
-    __global__ void __launch_bounds__(128, (NB <= 6 ? 4 : 3)) helm_mfma_kernel(HelmArgs A, const double *__restrict__ PS, const double *__restrict__ DS,
+    template <int NB, int NQS, int NQM, bool NATIVE = false, int NCS = 0, int NCM = 0, int OCC = 0>
+    __global__ void __launch_bounds__(128, (OCC ? OCC : NB <= 6 ? 4 : 3)) helm_mfma_kernel(HelmArgs A, const double *__restrict__ PS, const double *__restrict__ DS,
                                                               const double *__restrict__ PM, const double *__restrict__ PF,
                                                               const double *__restrict__ Gm, long long gm_stride,
                                                               const double *__restrict__ Am, long long am_stride)
@@ -2152,7 +2152,7 @@ namespace
         // (round 3, native ordering, same-box A/B of build variants at n_basis 6, profiles/r03/config5_ab.txt: 3 wavefronts per SIMD
         // 126.5 -> 142 us, with two / four slices per trip 137 us, two mass slices per trip at 4 wavefronts 131 us, the element ->
         // local dof map re-read before the colour phases instead of held in registers 128 us -- none kept)
-        constexpr int GS = NB == 7 ? 2 : 1, GM = NB == 7 ? 4 : 1;
+        constexpr int GS = (NB == 7 && NCS == 0) ? 2 : 1, GM = (NB == 7 && NCS == 0) ? 4 : 1; // (staged: slices come from LDS, one at a time)
         // forward products (rows = quadrature points) on v_mfma_f64_4x4x4 like the backward ones: JS row blocks x KB xi blocks
         // instead of 16 padded rows per k-step (n_basis 6: 7 of 16 rows were real).  Same-box A/B: n_basis 6 +2 %, 7 +2 %;
         // n_basis 8 (three row blocks, spills) -9 %, so it keeps the 16x16x4 form
@@ -2165,29 +2165,168 @@ namespace
         const int cmp = threadIdx.x >> 6; // component of this wavefront
         const int ML = A.max_loc;
         double *xy = lds; // [2][ML]: first the gathered x, then the accumulated y
-        const int off = A.dof_off[patch];
-        const int nloc = A.dof_off[patch + 1] - off;
-        const int *dofs = A.dof_list + off;
-        const bool active = e < A.patch_nel[patch];
-        const int mycol = active ? A.colour[patch * PEM + e] : -1;
-        const uint32_t *li = A.lidx + (size_t)patch * NP * PEM + e;
-        int id[2][NB];
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-            for (int l = 0; l < NB; ++l)
+        auto stamp = [&](int k) // diagnostic, as in helm_lane_kernel (wavefront 0 of the batch)
+        {
+            if (A.stamps)
             {
-                const int n = g + 4 * s + NB * l;
-                const uint32_t w = (g + 4 * s < NB) ? li[(n >> 1) * PEM] : 0u;
-                id[s][l] = (n & 1) ? static_cast<int>(w >> 16) : static_cast<int>(w & 0xFFFFu);
+                unsigned long long t;
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+                if (threadIdx.x == 0)
+                    A.stamps[(size_t)patch * 8 + k] = t;
             }
-
-        constexpr int ROWS = 7; // 128 threads x 7 = 896 dofs per pass: a 4x4-element batch of n_basis 8 (841) in one
-        int own0 = 0, nown = 0;
+        };
+        stamp(0);
+        // STAGE (NCS > 0): the batch's metric data (3 NQS^2 + NQM^2 doubles per element, contiguous per batch) travels in NCS + NCM
+        // chunks of whole slices through one LDS buffer behind xy: the 128 threads request chunk k + 1 (16 bytes per thread and piece,
+        // held in registers) before the slices of chunk k are worked from LDS, and park it when those are done.  A slice then costs
+        // no dependent trip to memory, the two wavefronts share one copy, and the requests are whole lines.
+        constexpr bool STAGE = NCS > 0;
+        constexpr int HS = STAGE ? (NQS + NCS - 1) / NCS : NQS, HM = STAGE ? (NQM + NCM - 1) / NCM : NQM; // slices per chunk
+        constexpr int CS2 = HS * 3 * NQS * PEM / 2, CM2 = HM * NQM * PEM / 2;                                // dbl2 per (full) chunk
+        constexpr int CH2 = CS2 > CM2 ? CS2 : CM2, RC = (CH2 + 127) / 128;
+        double *mC = lds + 2 * ((ML + 1) & ~1);
+        dbl2_t nx[STAGE ? RC : 1];
+        const dbl2_t *gsrc = reinterpret_cast<const dbl2_t *>(Gm + (size_t)patch * gm_stride);
+        const dbl2_t *asrc = reinterpret_cast<const dbl2_t *>(Am + (size_t)patch * am_stride);
+        // chunk c of the sequence [stiffness 0 .. NCS-1, mass 0 .. NCM-1]: request (clamped addresses, no branches) / park
+        auto chunk_request = [&](int c)
+        {
+            const bool st = c < NCS;
+            const int h = st ? c : c - NCS;
+            const int first = st ? h * HS : h * HM, cnt = st ? min(HS, NQS - first) : min(HM, NQM - first);
+            const dbl2_t *src = st ? gsrc + first * (3 * NQS * PEM / 2) : asrc + first * (NQM * PEM / 2);
+            const int n2 = cnt * (st ? 3 * NQS * PEM / 2 : NQM * PEM / 2);
+#pragma unroll
+            for (int j = 0; j < RC; ++j)
+                nx[j] = __builtin_nontemporal_load(src + min(128 * j + (int)threadIdx.x, n2 - 1));
+            return n2;
+        };
+        auto chunk_park = [&](int n2)
+        {
+#pragma unroll
+            for (int j = 0; j < RC; ++j)
+                if (128 * j + (int)threadIdx.x < n2)
+                    reinterpret_cast<dbl2_t *>(mC)[128 * j + threadIdx.x] = nx[j];
+        };
+        // FASTG (staged native form): everything whose address is known at kernel entry is requested in one burst and without
+        // branches (a load under a condition becomes its own basic block and drains the queue first).  The batch's few scalars come
+        // through the scalar cache; then, oldest first because the counter is in order: border positions, the owned rows of x,
+        // chunk 0, colours and the element -> local dof map.  What remains dependent is border position -> x for the border rows
+        // (phase stamps before: four trips in a row, 4.7 of a batch's 20 us)
+        constexpr bool FASTG = NATIVE && STAGE;
+        constexpr int GR = NB == 5 ? 3 : NB == 6 ? 4 : NB == 7 ? 5 : 7; // rows of 128 that hold a 4x4-element batch
+        int off, nloc, nel, own0 = 0, nown = 0;
         const int *bp = nullptr, *bs = nullptr;
         const int bcap = A.bstride - 1;
         const dbl2_t *X2 = reinterpret_cast<const dbl2_t *>(A.x);
-        if constexpr (NATIVE)
+        int pb[FASTG ? GR : 1];
+        dbl2_t xo[FASTG ? GR : 1];
+        if constexpr (FASTG)
+        {
+            unsigned long long d2, o2;
+            asm volatile("s_load_dwordx2 %0, %3, 0x0\n\ts_load_dwordx2 %1, %4, 0x0\n\ts_load_dword %2, %5, 0x0\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&s"(d2), "=&s"(o2), "=&s"(nel)
+                         : "s"(A.dof_off + patch), "s"(A.own_off + patch), "s"(A.patch_nel + patch));
+            off = static_cast<int>(d2 & 0xFFFFFFFFull);
+            nloc = static_cast<int>(d2 >> 32) - off;
+            own0 = static_cast<int>(o2 & 0xFFFFFFFFull);
+            nown = static_cast<int>(o2 >> 32) - own0;
+            bp = A.bpos + (size_t)patch * A.bstride;
+            bs = A.bslot + (size_t)patch * A.bstride;
+            const int last_own = own0 + max(nown - 1, 0);
+#pragma unroll
+            for (int j = 0; j < GR; ++j)
+                pb[j] = bp[max(0, min(128 * j + (int)threadIdx.x - nown, bcap))];
+#pragma unroll
+            for (int j = 0; j < GR; ++j)
+                xo[j] = X2[min(own0 + 128 * j + (int)threadIdx.x, last_own)]; // owned rows: no dependence on the list
+        }
+        int n2_next = 0;
+        if constexpr (STAGE)
+            n2_next = chunk_request(0);
+        const uint32_t *li = A.lidx + (size_t)patch * NP * PEM + e;
+        // the batch's element -> local dof map (NP x 16 words) and colours are parked in LDS too (behind the chunk buffer): twelve
+        // registers fewer through the slices, and whole-line requests instead of twelve scattered ones per lane
+        constexpr int LW = NP * PEM, LWR = (LW + 127) / 128;
+        uint32_t *lw = reinterpret_cast<uint32_t *>(mC + 2 * CH2);
+        int *colL = reinterpret_cast<int *>(lw + LW);
+        uint32_t lwr[FASTG ? LWR : 1];
+        int col_raw = -1;
+        if constexpr (FASTG)
+        {
+            col_raw = A.colour[patch * PEM + e];
+#pragma unroll
+            for (int j = 0; j < LWR; ++j)
+                lwr[j] = A.lidx[(size_t)patch * LW + min(128 * j + (int)threadIdx.x, LW - 1)];
+        }
+        else
+        {
+            off = A.dof_off[patch];
+            nloc = A.dof_off[patch + 1] - off;
+            nel = A.patch_nel[patch];
+        }
+        const int *dofs = A.dof_list + off;
+        const bool active = e < nel;
+        int mycol = -1;
+        if constexpr (!FASTG)
+            mycol = active ? A.colour[patch * PEM + e] : -1;
+        int id[2][NB];
+        if constexpr (!FASTG)
+        {
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int l = 0; l < NB; ++l)
+                {
+                    const int n = g + 4 * s + NB * l;
+                    const uint32_t w = (g + 4 * s < NB) ? li[(n >> 1) * PEM] : 0u;
+                    id[s][l] = (n & 1) ? static_cast<int>(w >> 16) : static_cast<int>(w & 0xFFFFu);
+                }
+        }
+        auto local_id = [&](int s, int l) -> int // node g + 4 s + NB l of this lane's element
+        {
+            if constexpr (FASTG)
+            {
+                const int n = g + 4 * s + NB * l; // (g + 4 s >= NB: some other node's id, a valid LDS index; the caller discards the value)
+                const uint32_t w = lw[min(n >> 1, NP - 1) * PEM + e];
+                return (n & 1) ? static_cast<int>(w >> 16) : static_cast<int>(w & 0xFFFFu);
+            }
+            else
+                return id[s][l];
+        };
+
+        constexpr int ROWS = 7; // 128 threads x 7 = 896 dofs per pass: a 4x4-element batch of n_basis 8 (841) in one
+        if constexpr (FASTG)
+        {
+            {
+                // straight-line (a loop's header would wait for the burst above before the first request goes out); the values are
+                // pinned before the guarded LDS writes, or the compiler sinks a row's loads into its guard, one drained trip each
+                dbl2_t xb[GR];
+#pragma unroll
+                for (int j = 0; j < GR; ++j)
+                    xb[j] = X2[pb[j]];
+#pragma unroll
+                for (int j = 0; j < GR; ++j)
+                    asm volatile("" : "+v"(xo[j].x), "+v"(xo[j].y), "+v"(xb[j].x), "+v"(xb[j].y));
+#pragma unroll
+                for (int j = 0; j < GR; ++j)
+                {
+                    const int i = 128 * j + (int)threadIdx.x;
+                    if (i < nloc)
+                    {
+                        xy[i] = i < nown ? xo[j].x : xb[j].x;
+                        xy[ML + i] = i < nown ? xo[j].y : xb[j].y;
+                    }
+                }
+            }
+            for (int i = 128 * GR + (int)threadIdx.x; i < nloc; i += 128) // a batch that is not a 4x4 block (irregular meshes)
+            {
+                const dbl2_t t = X2[i < nown ? own0 + i : bp[min(i - nown, bcap)]];
+                xy[i] = t.x;
+                xy[ML + i] = t.y;
+            }
+        }
+        else if constexpr (NATIVE)
         {
             own0 = A.own_off[patch];
             nown = A.own_off[patch + 1] - own0;
@@ -2248,14 +2387,46 @@ namespace
                 }
             }
         }
+        if constexpr (STAGE)
+            chunk_park(n2_next);
+        if constexpr (FASTG)
+        {
+#pragma unroll
+            for (int j = 0; j < LWR; ++j)
+                if (128 * j + (int)threadIdx.x < LW)
+                    lw[128 * j + threadIdx.x] = lwr[j];
+            if (threadIdx.x < PEM)
+                colL[threadIdx.x] = col_raw;
+        }
         __syncthreads();
+        stamp(1); // x (and the staged metric data) in LDS
         double U[1][2][NB], OUT[1][2][NB]; // [this wave's component][s][l]
+        if constexpr (FASTG)
+        {
+            // without branches: all ids, then all values (lanes without an element or a node read valid LDS and discard)
+            int il[2][NB];
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int l = 0; l < NB; ++l)
+                    il[s][l] = local_id(s, l);
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int l = 0; l < NB; ++l)
+                {
+                    const double t = xy[cmp * ML + il[s][l]];
+                    U[0][s][l] = (active && g + 4 * s < NB) ? t : 0.0;
+                    OUT[0][s][l] = 0.0;
+                }
+        }
+        else
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
             for (int l = 0; l < NB; ++l)
             {
-                U[0][s][l] = (active && g + 4 * s < NB) ? xy[cmp * ML + id[s][l]] : 0.0;
+                U[0][s][l] = (active && g + 4 * s < NB) ? xy[cmp * ML + local_id(s, l)] : 0.0;
                 OUT[0][s][l] = 0.0;
             }
         __syncthreads();
@@ -2266,6 +2437,7 @@ namespace
         }
         __syncthreads();
 
+        stamp(2); // element values in registers, LDS cleared
         // ------------------------------------------------------------ stiffness slices
         {
             constexpr int KB = (NB + 3) / 4; // backward products on v_mfma_f64_4x4x4_f64, as in op_mfma_kernel
@@ -2306,9 +2478,14 @@ namespace
             const double *Gb = Gm + (size_t)patch * gm_stride + e;
             // GS slices travel together (a slice is 3 JS doubles per lane, 3 KB per wavefront); the fence keeps the group's loads
             // ahead of its arithmetic in the generated code
+            if constexpr (STAGE) // the coefficient tables above have landed: the loop's waits must not count the chunk requests it issues
+                __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
 #pragma unroll 1
             for (int r0 = 0; r0 < NQS; r0 += GS)
             {
+                if constexpr (STAGE)
+                    if (r0 % HS == 0) // a chunk begins: its successor is requested now and parked when this chunk's slices are done
+                        n2_next = chunk_request(r0 / HS + 1);
                 double gaG[GS][JS], gbG[GS][JS], gcG[GS][JS];
 #pragma unroll
                 for (int gi = 0; gi < GS; ++gi)
@@ -2318,9 +2495,19 @@ namespace
                         const int q = 4 * j + g, rr = min(r0 + gi, NQS - 1);
                         const bool ok = q < NQS;
                         const size_t o = (((size_t)rr * 3) * NQS + (ok ? q : 0)) * PEM;
-                        gaG[gi][j] = ok ? Gb[o] : 0.0;
-                        gbG[gi][j] = ok ? Gb[o + (size_t)NQS * PEM] : 0.0;
-                        gcG[gi][j] = ok ? Gb[o + (size_t)2 * NQS * PEM] : 0.0;
+                        if constexpr (STAGE)
+                        {
+                            const int ol = (((rr % HS) * 3) * NQS + (ok ? q : 0)) * PEM + e;
+                            gaG[gi][j] = ok ? mC[ol] : 0.0;
+                            gbG[gi][j] = ok ? mC[ol + NQS * PEM] : 0.0;
+                            gcG[gi][j] = ok ? mC[ol + 2 * NQS * PEM] : 0.0;
+                        }
+                        else
+                        {
+                            gaG[gi][j] = ok ? Gb[o] : 0.0;
+                            gbG[gi][j] = ok ? Gb[o + (size_t)NQS * PEM] : 0.0;
+                            gcG[gi][j] = ok ? Gb[o + (size_t)2 * NQS * PEM] : 0.0;
+                        }
                     }
                 asm volatile("" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
@@ -2399,12 +2586,20 @@ namespace
                     for (int s = 0; s < 2; ++s)
 #pragma unroll
                         for (int l = 0; l < NB; ++l)
-                            OUT[c][s][l] += PS[r + NQS * l] * W0[s] + DS[r + NQS * l] * W1[s];
+                            OUT[c][s][l] = fma(PS[r + NQS * l], W0[s], fma(DS[r + NQS * l], W1[s], OUT[c][s][l])); // two FMAs (the sum form compiles to mul + fma + add)
                     }
                 }
+                if constexpr (STAGE)
+                    if ((r0 + 1) % HS == 0 || r0 + 1 == NQS) // the chunk's last slice: both wavefronts are done with the buffer
+                    {
+                        __syncthreads();
+                        chunk_park(n2_next);
+                        __syncthreads();
+                    }
             }
         }
 
+        stamp(3); // stiffness slices done
         // ------------------------------------------------------------ mass slices: out -= w^2 M u
         {
             const double w2 = -A.omega * A.omega;
@@ -2438,9 +2633,14 @@ namespace
                     AbP[rb][sp] = (k < NB && q < NQM) ? PM[q + NQM * k] : 0.0;
                 }
             const double *ab = Am + (size_t)patch * am_stride + e;
+            if constexpr (STAGE)
+                __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0), as above
 #pragma unroll 1
             for (int r0 = 0; r0 < NQM; r0 += GM)
             {
+                if constexpr (STAGE)
+                    if (r0 % HM == 0 && r0 / HM + 1 < NCM)
+                        n2_next = chunk_request(NCS + r0 / HM + 1);
                 double amG[GM][JM];
 #pragma unroll
                 for (int gi = 0; gi < GM; ++gi)
@@ -2448,7 +2648,10 @@ namespace
                     for (int j = 0; j < JM; ++j)
                     {
                         const int q = 4 * j + g, rr = min(r0 + gi, NQM - 1);
-                        amG[gi][j] = q < NQM ? ab[((size_t)rr * NQM + q) * PEM] : 0.0;
+                        if constexpr (STAGE)
+                            amG[gi][j] = q < NQM ? mC[((rr % HM) * NQM + q) * PEM + e] : 0.0;
+                        else
+                            amG[gi][j] = q < NQM ? ab[((size_t)rr * NQM + q) * PEM] : 0.0;
                     }
                 asm volatile("" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
@@ -2512,10 +2715,36 @@ namespace
                             OUT[c][s][l] += PM[r + NQM * l] * W[s];
                     }
                 }
+                if constexpr (STAGE)
+                    if ((r0 + 1) % HM == 0 && r0 + 1 < NQM)
+                    {
+                        __syncthreads();
+                        chunk_park(n2_next);
+                        __syncthreads();
+                    }
             }
         }
 
+        stamp(4); // mass slices done
         // ------------------------------------------------------------ accumulate in colour phases; the v row is negated
+        int ilc[2][NB];
+        if constexpr (FASTG)
+        {
+            mycol = active ? colL[e] : -1;
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int l = 0; l < NB; ++l)
+                    ilc[s][l] = local_id(s, l);
+        }
+        else
+        {
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int l = 0; l < NB; ++l)
+                    ilc[s][l] = id[s][l];
+        }
         for (int c = 0; c < A.ncol; ++c)
         {
             if (mycol == c)
@@ -2525,19 +2754,21 @@ namespace
                     if (g + 4 * s < NB)
                     {
                         double acc[NB]; // loads first, then adds and stores (see helm_lane_kernel)
+                        const int(&il)[NB] = ilc[s];
 #pragma unroll
                         for (int l = 0; l < NB; ++l)
-                            acc[l] = xy[cmp * ML + id[s][l]];
+                            acc[l] = xy[cmp * ML + il[l]];
                         asm volatile("" ::: "memory"); // all loads before all stores, also in the generated code (the scheduler
                         __builtin_amdgcn_sched_barrier(0); // otherwise re-serialises them to save registers)
 #pragma unroll
                         for (int l = 0; l < NB; ++l)
-                            xy[cmp * ML + id[s][l]] = acc[l] + (cmp ? -OUT[0][s][l] : OUT[0][s][l]);
+                            xy[cmp * ML + il[l]] = acc[l] + (cmp ? -OUT[0][s][l] : OUT[0][s][l]);
                     }
             }
             __syncthreads();
         }
 
+        stamp(5); // colour phases done
         // ------------------------------------------------------------ boundary faces:  Au -= w H v,  Av -= w H u
         {
             const int f_begin = A.face_off[patch], nf = A.face_off[patch + 1] - f_begin;
@@ -2601,6 +2832,7 @@ namespace
             }
         }
 
+        stamp(6); // faces done
         // ------------------------------------------------------------ write out
         if constexpr (NATIVE)
         {
@@ -2616,6 +2848,7 @@ namespace
                 else
                     P2[bs[min(i - nown, bcap)]] = r;
             }
+            stamp(7);
             return;
         }
         const int *slot = A.slot_of + off;
@@ -2640,10 +2873,56 @@ namespace
         }
     }
 
+    // How helm_mfma_kernel gets its metric data: 0 = one dependent trip to memory per slice; 100 w + 10 cs + cm = in cs + cm chunks
+    // requested one ahead and parked in LDS, w wavefronts per SIMD.  Same-box A/B (profiles/r03/mfma_stage_ab.txt): n_basis 6 and 7
+    // gain 6-9 % with 2 + 2 chunks; n_basis 8 (register spills at 3 wavefronts per SIMD, 2.5 by LDS) and n_basis 5 on the matrix cores
+    // do not.  CUDDH_HELM_MFMA_STAGE overrides (measurement knob; 0 = off).
+    int mfma_stage(int nb)
+    {
+        static const int knob = [] { const char *e = std::getenv("CUDDH_HELM_MFMA_STAGE"); return e ? std::atoi(e) : -1; }();
+        if (knob >= 0)
+            return knob;
+        return (nb == 6 || nb == 7) ? 322 : 0;
+    }
+
     template <int NB, int NQS, int NQM>
     void launch_helm_mfma(const cuddh_helmholtz_plan *p, const HelmArgs &A, hipStream_t st, bool native)
     {
         const dim3 grid(8 * A.xcd_chunk), block(128); // one wavefront per component
+        const int stage = mfma_stage(NB);
+        if (stage)
+        {
+            auto go = [&](auto nat, auto ncs, auto ncm, auto occ)
+            {
+                constexpr bool NAT = decltype(nat)::value;
+                constexpr int NCS = decltype(ncs)::value, NCM = decltype(ncm)::value, OCC = decltype(occ)::value;
+                constexpr int HS = (NQS + NCS - 1) / NCS, HM = (NQM + NCM - 1) / NCM;
+                constexpr int CH = (HS * 3 * NQS > HM * NQM ? HS * 3 * NQS : HM * NQM) * 16;
+                const size_t lds_s = ((size_t)2 * ((p->max_loc + 1) & ~1) + CH) * sizeof(double) + ((NB * NB + 1) / 2 * 16 + 16) * sizeof(int);
+                hipLaunchKernelGGL((helm_mfma_kernel<NB, NQS, NQM, NAT, NCS, NCM, OCC>), grid, block, lds_s, st, A, p->PS, p->DS, p->PM, p->PF, p->Gm, p->gm_stride, p->Am,
+                                   p->am_stride);
+            };
+            using std::integral_constant;
+            using std::true_type;
+            if (!native) // reference ordering: the default form only
+            {
+                go(std::false_type{}, integral_constant<int, 2>{}, integral_constant<int, 2>{}, integral_constant<int, 3>{});
+                return;
+            }
+#define CUDDH_STAGE_CASE(o, cs, cm)                                                                                  \
+    if (stage == 100 * o + 10 * cs + cm)                                                                             \
+    {                                                                                                                \
+        go(true_type{}, integral_constant<int, cs>{}, integral_constant<int, cm>{}, integral_constant<int, o>{});   \
+        return;                                                                                                      \
+    }
+            CUDDH_STAGE_CASE(3, 2, 2)
+            CUDDH_STAGE_CASE(3, 2, 1)
+            CUDDH_STAGE_CASE(3, 3, 2)
+            CUDDH_STAGE_CASE(2, 2, 2)
+#undef CUDDH_STAGE_CASE
+            std::fprintf(stderr, "CUDDH_HELM_MFMA_STAGE=%d is not a built variant (322, 321, 332, 222)\n", stage);
+            std::abort();
+        }
         const size_t lds = (size_t)2 * p->max_loc * sizeof(double);
         if (native)
             hipLaunchKernelGGL((helm_mfma_kernel<NB, NQS, NQM, true>), grid, block, lds, st, A, p->PS, p->DS, p->PM, p->PF, p->Gm, p->gm_stride, p->Am, p->am_stride);
@@ -3244,7 +3523,7 @@ extern "C"
             (*out)->prefetch = 0;
             if (const char *e = std::getenv("CUDDH_HELM_PRE"))
                 (*out)->prefetch = (*out)->lane_form && std::atoi(e) != 0;
-            if (std::getenv("CUDDH_HELM_STAMPS") && (*out)->lane_form) // diagnostic, see cuddh_hip_helmholtz_plan_read_stamps
+            if (std::getenv("CUDDH_HELM_STAMPS") && ((*out)->lane_form || (*out)->pe == 16)) // diagnostic, see cuddh_hip_helmholtz_plan_read_stamps
                 if (hipMalloc(reinterpret_cast<void **>(&(*out)->stamps), (size_t)(*out)->n_patches * 8 * sizeof(unsigned long long)) == hipSuccess)
                     (void)hipMemset((*out)->stamps, 0, (size_t)(*out)->n_patches * 8 * sizeof(unsigned long long));
         }
@@ -3427,7 +3706,13 @@ extern "C"
         const int kind = p->nqS > 0 ? 0 : 1, nq = kind == 0 ? p->nqS : p->nqM;
         const bool nt = p->streaming != 0;
         if (fused && p->Gm && p->Am)
-            std::snprintf(buf, cap, "helm_mfma_kernel<%d,%d,%d> pe=16 affine=%d", p->nb, p->nqS, p->nqM, p->gm_stride == 0 ? 1 : 0);
+            {
+                const int stg = mfma_stage(p->nb);
+                if (stg)
+                    std::snprintf(buf, cap, "helm_mfma_kernel<%d,%d,%d,chunks=%d+%d> pe=16 affine=%d", p->nb, p->nqS, p->nqM, (stg / 10) % 10, stg % 10, p->gm_stride == 0 ? 1 : 0);
+                else
+                    std::snprintf(buf, cap, "helm_mfma_kernel<%d,%d,%d> pe=16 affine=%d", p->nb, p->nqS, p->nqM, p->gm_stride == 0 ? 1 : 0);
+            }
         else if (fused && p->nb <= 4 && p->pe == 64 && p->lane_form)
             std::snprintf(buf, cap, "helm_lane_kernel<%d,%d,%d,NT=%d,UG=%d%s> pe=64", p->nb, p->nqS, p->nqM, nt, p->Gu ? 1 : 0, p->prefetch ? ",PRE=1" : "");
         else if (fused)
