@@ -2429,15 +2429,20 @@ namespace
                 U[0][s][l] = (active && g + 4 * s < NB) ? xy[cmp * ML + local_id(s, l)] : 0.0;
                 OUT[0][s][l] = 0.0;
             }
-        __syncthreads();
-        for (int i = threadIdx.x; i < nloc; i += 128)
+        // xy becomes the accumulator y: cleared once every thread has its values.  Staged form: between the two barriers at which the
+        // first chunk is parked (nobody touches xy during the slices), so the clear costs no barrier of its own.
+        if constexpr (!STAGE)
         {
-            xy[i] = 0.0;
-            xy[ML + i] = 0.0;
+            __syncthreads();
+            for (int i = threadIdx.x; i < nloc; i += 128)
+            {
+                xy[i] = 0.0;
+                xy[ML + i] = 0.0;
+            }
+            __syncthreads();
         }
-        __syncthreads();
 
-        stamp(2); // element values in registers, LDS cleared
+        stamp(2); // element values in registers (unstaged form: and LDS cleared)
         // ------------------------------------------------------------ stiffness slices
         {
             constexpr int KB = (NB + 3) / 4; // backward products on v_mfma_f64_4x4x4_f64, as in op_mfma_kernel
@@ -2594,6 +2599,12 @@ namespace
                     {
                         __syncthreads();
                         chunk_park(n2_next);
+                        if (r0 + 1 == (HS < NQS ? HS : NQS)) // first park: everybody has read its values from xy (see above)
+                            for (int i = threadIdx.x; i < nloc; i += 128)
+                            {
+                                xy[i] = 0.0;
+                                xy[ML + i] = 0.0;
+                            }
                         __syncthreads();
                     }
             }
