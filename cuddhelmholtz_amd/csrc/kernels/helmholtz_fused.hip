@@ -1283,10 +1283,23 @@ namespace
         const dbl2_t *p2 = reinterpret_cast<const dbl2_t *>(part); // a slot is the pair (u, v)
         for (int j = blockIdx.x * 256 + threadIdx.x; j < n_shared; j += gridDim.x * 256)
         {
+            // the slots of one dof are contiguous, in patch order; the first four are requested together (clamped addresses) and
+            // added in that order under a select -- one trip to memory instead of one per slot (a dof has 2-4 slots almost always)
+            const int t0 = shared_off[j], t1 = shared_off[j + 1], last = max(t1 - 1, t0);
+            dbl2_t q[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                q[k] = p2[min(t0 + k, last)];
             double su = 0.0, sv = 0.0;
-            for (int t = shared_off[j]; t < shared_off[j + 1]; ++t)
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
             {
-                const dbl2_t s = p2[t]; // the slots of one dof are contiguous, in patch order
+                su = t0 + k < t1 ? su + q[k].x : su;
+                sv = t0 + k < t1 ? sv + q[k].y : sv;
+            }
+            for (int t = t0 + 4; t < t1; ++t)
+            {
+                const dbl2_t s = p2[t];
                 su += s.x;
                 sv += s.y;
             }
@@ -1302,10 +1315,22 @@ namespace
     {
         for (int j = blockIdx.x * 256 + threadIdx.x; j < n_shared; j += gridDim.x * 256)
         {
+            // (as helm_border_kernel: same slots, same order, the first four requested together)
+            const int t0 = shared_off[j], t1 = shared_off[j + 1], last = max(t1 - 1, t0);
+            dbl2_t q[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                q[k] = part[min(t0 + k, last)];
             dbl2_t s = {0.0, 0.0};
-            for (int t = shared_off[j]; t < shared_off[j + 1]; ++t)
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
             {
-                s.x += part[t].x; // the slots of one dof are contiguous, in patch order (the order helm_border_kernel sums in)
+                s.x = t0 + k < t1 ? s.x + q[k].x : s.x;
+                s.y = t0 + k < t1 ? s.y + q[k].y : s.y;
+            }
+            for (int t = t0 + 4; t < t1; ++t)
+            {
+                s.x += part[t].x;
                 s.y += part[t].y;
             }
             y[n_owned + j] = s;
@@ -2960,9 +2985,18 @@ namespace
         for (int j = blockIdx.x * 256 + threadIdx.x; j < n_shared; j += gridDim.x * 256)
         {
             const int g = shared_dof[j];
+            // contiguous slots, patch order; the first four requested together (see helm_border_kernel)
+            const int t0 = shared_off[j], t1 = shared_off[j + 1], last = max(t1 - 1, t0);
+            double q[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                q[k] = part[min(t0 + k, last)];
             double s = accumulate ? y[g] : 0.0;
-            for (int t = shared_off[j]; t < shared_off[j + 1]; ++t)
-                s += part[t]; // contiguous slots, patch order
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                s = t0 + k < t1 ? s + q[k] : s;
+            for (int t = t0 + 4; t < t1; ++t)
+                s += part[t];
             y[g] = s;
         }
     }
