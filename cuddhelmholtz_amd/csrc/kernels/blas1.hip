@@ -88,14 +88,13 @@ namespace
 #pragma unroll
                 for (int u = 0; u < UNROLL; ++u)
                 {
-                    const int i = base + u * BLOCK;
-                    if (i < nv)
-                    {
-                        if (READ_X)
-                            a[u] = stream_load<NT>(xv + i);
-                        if (READ_Y)
-                            b[u] = stream_load<NT>(yv + i);
-                    }
+                    // clamped, not guarded: a request under `if (i < nv)` is a basic block of its own and the tile's requests
+                    // would go out one group at a time (see mgs_stage_kernel)
+                    const int i = min(base + u * BLOCK, nv - 1);
+                    if (READ_X)
+                        a[u] = stream_load<NT>(xv + i);
+                    if (READ_Y)
+                        b[u] = stream_load<NT>(yv + i);
                 }
 #pragma unroll
                 for (int u = 0; u < UNROLL; ++u)
@@ -234,13 +233,10 @@ namespace
 #pragma unroll
                 for (int u = 0; u < UNROLL; ++u)
                 {
-                    const int i = base + u * BLOCK;
-                    if (i < nv)
-                    {
-                        a[u] = stream_load<NT>(xv + i);
-                        if (MODE != 2)
-                            b[u] = stream_load<NT>(yv + i);
-                    }
+                    const int i = min(base + u * BLOCK, nv - 1); // (clamped, not guarded: see map_kernel)
+                    a[u] = stream_load<NT>(xv + i);
+                    if (MODE != 2)
+                        b[u] = stream_load<NT>(yv + i);
                 }
 #pragma unroll
                 for (int u = 0; u < UNROLL; ++u)
@@ -292,18 +288,52 @@ namespace
     //         w <- w - h * v_prev     (skipped when v_prev == nullptr: first stage)
     //         pout[block] = partial sum of <w, v_next>   (v_next == nullptr: <w, w>, for the norm)
     // Every workgroup sums the same <= MAX_PARTIALS partials in the same order, so all of them use the same h.
-    template <typename T>
+    // PREV / NEXT: v_prev / v_next given (compile-time, so that no request sits under a run-time condition).  A workgroup's FIRST tile
+    // is requested before the coefficient is summed -- the requests do not depend on it -- with clamped addresses and no branches,
+    // and the <= 4 partial sums per thread go out with them: for vectors of a few MB (config 2: 9.5 MB) a stage is a chain of
+    // dependent trips, not a bandwidth problem, and the former form (requests under `if (i < nv)` inside the tile loop, whose header
+    // waits for everything outstanding; the partial sums in a loop of their own) made seven of them in a row
+    // (profiles/r03/mgs_stage_small_vectors.txt).
+    template <typename T, bool PREV, bool NEXT>
     __global__ void __launch_bounds__(BLOCK) mgs_stage_kernel(int n, T *__restrict__ w, const T *__restrict__ vprev, const T *__restrict__ vnext,
                                                               const T *__restrict__ pin, int npin, T *__restrict__ pout, T *__restrict__ hout,
                                                               int vectorised)
     {
         __shared__ T h_sh;
-        T h = T(0);
-        if (vprev)
+        using VE = T __attribute__((ext_vector_type(Pack<T>::N)));
+        constexpr int N = Pack<T>::N;
+        const int nv = vectorised ? n / N : 0;
+        const int n_tiles = (nv + TILE - 1) / TILE;
+        VE *wv = reinterpret_cast<VE *>(w);
+        const VE *pv = reinterpret_cast<const VE *>(vprev), *nvv = reinterpret_cast<const VE *>(vnext);
+        int tile = blockIdx.x;
+        const bool first = tile < n_tiles; // (workgroup-uniform)
+        VE a0[UNROLL], b0[UNROLL], c0[UNROLL];
+        if (first)
         {
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u)
+            {
+                const int i = min(tile * TILE + (int)threadIdx.x + u * BLOCK, nv - 1);
+                a0[u] = wv[i];
+                if constexpr (PREV)
+                    b0[u] = pv[i];
+                if constexpr (NEXT)
+                    c0[u] = nvv[i];
+            }
+        }
+        T h = T(0);
+        if constexpr (PREV)
+        {
+            static_assert(MAX_PARTIALS <= 4 * BLOCK, "four partial sums per thread");
+            T q[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                q[k] = pin[min((int)threadIdx.x + k * BLOCK, npin - 1)];
             T a = T(0);
-            for (int i = threadIdx.x; i < npin; i += BLOCK)
-                a += pin[i];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                a = (int)threadIdx.x + k * BLOCK < npin ? a + q[k] : a; // (the order of the former loop)
             const T s = block_sum(a);
             if (threadIdx.x == 0)
             {
@@ -315,64 +345,70 @@ namespace
             h = h_sh;
         }
         T acc = T(0);
-        using V = typename Pack<T>::type;
-        constexpr int N = Pack<T>::N;
         const int tid = blockIdx.x * BLOCK + threadIdx.x, stride = gridDim.x * BLOCK;
-        int done = 0;
-        if (vectorised)
+        if (first)
         {
-            // three streams in, one out, 16 bytes per lane and access; contiguous tiles taken in order (see the top of the file)
-            using VE = T __attribute__((ext_vector_type(Pack<T>::N)));
-            const int nv = n / N;
-            const int n_tiles = (nv + TILE - 1) / TILE;
-            VE *wv = reinterpret_cast<VE *>(w);
-            const VE *pv = reinterpret_cast<const VE *>(vprev), *nvv = reinterpret_cast<const VE *>(vnext);
-            for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x)
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u)
             {
-                const int base = tile * TILE + threadIdx.x;
-                VE a[UNROLL], b[UNROLL], c[UNROLL];
-#pragma unroll
-                for (int u = 0; u < UNROLL; ++u)
+                const int i = tile * TILE + (int)threadIdx.x + u * BLOCK;
+                if (i < nv)
                 {
-                    const int i = base + u * BLOCK;
-                    if (i < nv)
-                    {
-                        a[u] = wv[i];
-                        if (vprev)
-                            b[u] = pv[i];
-                        if (vnext)
-                            c[u] = nvv[i];
-                    }
-                }
 #pragma unroll
-                for (int u = 0; u < UNROLL; ++u)
-                {
-                    const int i = base + u * BLOCK;
-                    if (i < nv)
+                    for (int e = 0; e < N; ++e)
                     {
-#pragma unroll
-                        for (int e = 0; e < N; ++e)
-                        {
-                            if (vprev)
-                                a[u][e] -= h * b[u][e];
-                            acc += a[u][e] * (vnext ? c[u][e] : a[u][e]);
-                        }
-                        if (vprev)
-                            wv[i] = a[u];
+                        if constexpr (PREV)
+                            a0[u][e] -= h * b0[u][e];
+                        acc += a0[u][e] * (NEXT ? c0[u][e] : a0[u][e]);
                     }
+                    if constexpr (PREV)
+                        wv[i] = a0[u];
                 }
             }
-            done = nv * N;
+            tile += gridDim.x;
         }
-        for (int i = done + tid; i < n; i += stride)
+        // further tiles (vectors of more than MAX_PARTIALS tiles, 16 MB: enough workgroups in flight to hide the trips)
+        for (; tile < n_tiles; tile += gridDim.x)
+        {
+            const int base = tile * TILE + threadIdx.x;
+            VE a[UNROLL], b[UNROLL], c[UNROLL];
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u)
+            {
+                const int i = min(base + u * BLOCK, nv - 1); // (clamped, not guarded: all requests of a tile go out together)
+                a[u] = wv[i];
+                if constexpr (PREV)
+                    b[u] = pv[i];
+                if constexpr (NEXT)
+                    c[u] = nvv[i];
+            }
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u)
+            {
+                const int i = base + u * BLOCK;
+                if (i < nv)
+                {
+#pragma unroll
+                    for (int e = 0; e < N; ++e)
+                    {
+                        if constexpr (PREV)
+                            a[u][e] -= h * b[u][e];
+                        acc += a[u][e] * (NEXT ? c[u][e] : a[u][e]);
+                    }
+                    if constexpr (PREV)
+                        wv[i] = a[u];
+                }
+            }
+        }
+        for (int i = nv * N + tid; i < n; i += stride)
         {
             T wi = w[i];
-            if (vprev)
+            if constexpr (PREV)
             {
                 wi -= h * vprev[i];
                 w[i] = wi;
             }
-            acc += wi * (vnext ? vnext[i] : wi);
+            acc += wi * (NEXT ? vnext[i] : wi);
         }
         __syncthreads(); // block_sum reuses its LDS scratch
         const T s = block_sum(acc);
@@ -386,9 +422,28 @@ namespace
                                                                int vectorised)
     {
         __shared__ T nrm_sh;
+        using VE = T __attribute__((ext_vector_type(Pack<T>::N)));
+        constexpr int N = Pack<T>::N;
+        const int nv = vectorised ? n / N : 0;
+        const int n_tiles = (nv + TILE - 1) / TILE;
+        VE *wv = reinterpret_cast<VE *>(w);
+        int tile = blockIdx.x;
+        const bool first = tile < n_tiles; // the first tile is requested before the norm is summed (see mgs_stage_kernel)
+        VE a0[UNROLL];
+        if (first)
+        {
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u)
+                a0[u] = wv[min(tile * TILE + (int)threadIdx.x + u * BLOCK, nv - 1)];
+        }
+        T q[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            q[k] = pin[min((int)threadIdx.x + k * BLOCK, npin - 1)];
         T a = T(0);
-        for (int i = threadIdx.x; i < npin; i += BLOCK)
-            a += pin[i];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            a = (int)threadIdx.x + k * BLOCK < npin ? a + q[k] : a;
         const T s = block_sum(a);
         if (threadIdx.x == 0)
         {
@@ -398,37 +453,41 @@ namespace
         }
         __syncthreads();
         const T nrm = nrm_sh;
-        using V = typename Pack<T>::type;
-        constexpr int N = Pack<T>::N;
         const int tid = blockIdx.x * BLOCK + threadIdx.x, stride = gridDim.x * BLOCK;
-        int done = 0;
-        if (vectorised)
+        if (first)
         {
-            using VE = T __attribute__((ext_vector_type(Pack<T>::N)));
-            const int nv = n / N;
-            const int n_tiles = (nv + TILE - 1) / TILE;
-            VE *wv = reinterpret_cast<VE *>(w);
-            for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x)
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u)
             {
-                const int base = tile * TILE + threadIdx.x;
-                VE a[UNROLL];
+                const int i = tile * TILE + (int)threadIdx.x + u * BLOCK;
+                if (i < nv)
+                {
 #pragma unroll
-                for (int u = 0; u < UNROLL; ++u)
-                    if (base + u * BLOCK < nv)
-                        a[u] = wv[base + u * BLOCK];
-#pragma unroll
-                for (int u = 0; u < UNROLL; ++u)
-                    if (base + u * BLOCK < nv)
-                    {
-#pragma unroll
-                        for (int c = 0; c < N; ++c)
-                            a[u][c] = a[u][c] / nrm;
-                        wv[base + u * BLOCK] = a[u];
-                    }
+                    for (int c = 0; c < N; ++c)
+                        a0[u][c] = a0[u][c] / nrm;
+                    wv[i] = a0[u];
+                }
             }
-            done = nv * N;
+            tile += gridDim.x;
         }
-        for (int i = done + tid; i < n; i += stride)
+        for (; tile < n_tiles; tile += gridDim.x)
+        {
+            const int base = tile * TILE + threadIdx.x;
+            VE av[UNROLL];
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u)
+                av[u] = wv[min(base + u * BLOCK, nv - 1)];
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u)
+                if (base + u * BLOCK < nv)
+                {
+#pragma unroll
+                    for (int c = 0; c < N; ++c)
+                        av[u][c] = av[u][c] / nrm;
+                    wv[base + u * BLOCK] = av[u];
+                }
+        }
+        for (int i = nv * N + tid; i < n; i += stride)
             w[i] = w[i] / nrm;
     }
 
@@ -439,7 +498,16 @@ namespace
     {
         const int g = mgs_grid(n);
         const int vec = aligned16(w) && (!vprev || aligned16(vprev)) && (!vnext || aligned16(vnext));
-        hipLaunchKernelGGL((mgs_stage_kernel<T>), dim3(g), dim3(BLOCK), 0, as_stream(stream), n, w, vprev, vnext, pin, g, pout, hout, vec);
+        const dim3 grid(g), block(BLOCK);
+        hipStream_t st = as_stream(stream);
+        if (vprev && vnext)
+            hipLaunchKernelGGL((mgs_stage_kernel<T, true, true>), grid, block, 0, st, n, w, vprev, vnext, pin, g, pout, hout, vec);
+        else if (vprev)
+            hipLaunchKernelGGL((mgs_stage_kernel<T, true, false>), grid, block, 0, st, n, w, vprev, vnext, pin, g, pout, hout, vec);
+        else if (vnext)
+            hipLaunchKernelGGL((mgs_stage_kernel<T, false, true>), grid, block, 0, st, n, w, vprev, vnext, pin, g, pout, hout, vec);
+        else
+            hipLaunchKernelGGL((mgs_stage_kernel<T, false, false>), grid, block, 0, st, n, w, vprev, vnext, pin, g, pout, hout, vec);
         return launch_status();
     }
 
