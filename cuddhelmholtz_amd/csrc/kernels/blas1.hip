@@ -283,6 +283,11 @@ namespace
         return launch_status();
     }
 
+    // explicit fused multiply-adds in the Gram-Schmidt kernels: left to the compiler, the fp32 stage kernel got packed multiplies + adds
+    // (two roundings) where the same expressions in another kernel became FMAs -- the results must not depend on that choice
+    __device__ inline double fmadd(double a, double b, double c) { return __builtin_fma(a, b, c); }
+    __device__ inline float fmadd(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
     // ---------------- fused modified Gram-Schmidt stage (one launch per projection instead of dot + reduce + axpy)
     // stage:  h = sum(pin)            (the coefficient <w, v_prev> whose partial sums the previous stage left behind)
     //         w <- w - h * v_prev     (skipped when v_prev == nullptr: first stage)
@@ -358,8 +363,8 @@ namespace
                     for (int e = 0; e < N; ++e)
                     {
                         if constexpr (PREV)
-                            a0[u][e] -= h * b0[u][e];
-                        acc += a0[u][e] * (NEXT ? c0[u][e] : a0[u][e]);
+                            a0[u][e] = fmadd(-h, b0[u][e], a0[u][e]);
+                        acc = fmadd(a0[u][e], NEXT ? c0[u][e] : a0[u][e], acc);
                     }
                     if constexpr (PREV)
                         wv[i] = a0[u];
@@ -392,8 +397,8 @@ namespace
                     for (int e = 0; e < N; ++e)
                     {
                         if constexpr (PREV)
-                            a[u][e] -= h * b[u][e];
-                        acc += a[u][e] * (NEXT ? c[u][e] : a[u][e]);
+                            a[u][e] = fmadd(-h, b[u][e], a[u][e]);
+                        acc = fmadd(a[u][e], NEXT ? c[u][e] : a[u][e], acc);
                     }
                     if constexpr (PREV)
                         wv[i] = a[u];
@@ -405,10 +410,10 @@ namespace
             T wi = w[i];
             if constexpr (PREV)
             {
-                wi -= h * vprev[i];
+                wi = fmadd(-h, vprev[i], wi);
                 w[i] = wi;
             }
-            acc += wi * (NEXT ? vnext[i] : wi);
+            acc = fmadd(wi, NEXT ? vnext[i] : wi, acc);
         }
         __syncthreads(); // block_sum reuses its LDS scratch
         const T s = block_sum(acc);
