@@ -691,6 +691,9 @@ namespace
     // the gather of the owned dofs is one 16-byte load per dof at an address known at kernel entry -- no index list, no dependent
     // index -> value round trip -- and their write-out one 16-byte store; only the border dofs (15 % of an 8 x 8-element patch
     // at n_basis 4) go through lists (native position for the gather, slot for the write-out).
+#ifndef HELM_LANE_FAST_GATHER
+#define HELM_LANE_FAST_GATHER 1 // (measurement: 0 = the native gather as a loop, scalars through vector loads)
+#endif
     template <int NB, int NQS, int NQM, bool NT, bool UG, bool PRE = false, bool NATIVE = false>
     __global__ void __launch_bounds__(64, PRE ? 1 : (NB == 2 ? 5 : (NB == 3 ? 3 : 2))) helm_lane_kernel(HelmArgs A, const double *__restrict__ PS, const double *__restrict__ DS,
                                                               const double *__restrict__ PM, const double *__restrict__ PF,
@@ -719,20 +722,67 @@ namespace
         stamp(0);
 
         // (fixed-stride lists: the first index requests do not wait for an offset load; `cap` = highest valid list index)
-        const int nloc = A.dof_off[patch + 1] - A.dof_off[patch];
-        const int off = A.dof_stride ? patch * A.dof_stride : A.dof_off[patch];
+        // FASTL (native ordering): the patch's scalars through the scalar cache and the gather written straight-line (see below)
+        constexpr bool FASTL = NATIVE && !PRE && HELM_LANE_FAST_GATHER;
+        int nloc, off, nel_s = 0, own0 = 0, nown = 0;
+        if constexpr (FASTL)
+        {
+            unsigned long long d2, o2;
+            asm volatile("s_load_dwordx2 %0, %3, 0x0\n\ts_load_dwordx2 %1, %4, 0x0\n\ts_load_dword %2, %5, 0x0\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&s"(d2), "=&s"(o2), "=&s"(nel_s)
+                         : "s"(A.dof_off + patch), "s"(A.own_off + patch), "s"(A.patch_nel + patch));
+            nloc = static_cast<int>(d2 >> 32) - static_cast<int>(d2 & 0xFFFFFFFFull);
+            off = A.dof_stride ? patch * A.dof_stride : static_cast<int>(d2 & 0xFFFFFFFFull);
+            own0 = static_cast<int>(o2 & 0xFFFFFFFFull);
+            nown = static_cast<int>(o2 >> 32) - own0;
+        }
+        else
+        {
+            nloc = A.dof_off[patch + 1] - A.dof_off[patch];
+            off = A.dof_stride ? patch * A.dof_stride : A.dof_off[patch];
+        }
         const int cap = A.dof_stride ? A.dof_stride - 1 : nloc - 1;
         const int *dofs = A.dof_list + off;
         const double *Gp = A.Gp + (size_t)patch * 3 * NQS * NQS * PEK; // pair layout, see load_pairs
         const double *ap = A.aMp + (size_t)patch * NQM * NQM * PEK;
 
-        const bool active = lane < A.patch_nel[patch];
+        constexpr int ROWS = 10; // 640 dofs per pass: an 8x8-element patch of n_basis 4 (625) in one
+        const dbl2_t *X2 = reinterpret_cast<const dbl2_t *>(A.x);
+        const int *bp = nullptr, *bs = nullptr;
+        const int bcap = A.bstride - 1;
+        // FASTL, oldest requests first (the counter is in order): the native positions of the first 128 border dofs, then the owned
+        // rows of x -- before anything else is asked for, and not inside a loop (its header would wait for whatever is outstanding)
+        int pbL[FASTL ? 2 : 1];
+        dbl2_t xoL[FASTL ? ROWS : 1];
+        if constexpr (FASTL)
+        {
+            bp = A.bpos + (size_t)patch * A.bstride;
+            bs = A.bslot + (size_t)patch * A.bstride;
+            pbL[0] = bp[min(lane, bcap)];
+            pbL[1] = bp[min(64 + lane, bcap)];
+            const int last = own0 + max(nown - 1, 0);
+#pragma unroll
+            for (int j = 0; j < ROWS; ++j)
+                xoL[j] = X2[min(own0 + 64 * j + lane, last)];
+        }
+        bool active;
+        if constexpr (FASTL)
+            active = lane < nel_s;
+        else
+            active = lane < A.patch_nel[patch];
         const uint32_t *li = A.lidx + ((size_t)patch * NP) * PEK + lane;
         uint32_t lpk[NP];
 #pragma unroll
         for (int j = 0; j < NP; ++j)
             lpk[j] = li[j * PEK];
-        const int mycol = active ? A.colour[patch * PEK + lane] : -1;
+        int mycol;
+        if constexpr (FASTL)
+        {
+            const int col_raw = A.colour[patch * PEK + lane]; // (padded to 64 lanes per patch)
+            mycol = active ? col_raw : -1;
+        }
+        else
+            mycol = active ? A.colour[patch * PEK + lane] : -1;
         auto load_stiff = [&](int q, double (&g)[3 * NQS])
         {
             if constexpr (UG)
@@ -779,20 +829,16 @@ namespace
         double gS[PRE ? NQS : 1][3 * NQS];
         double aW[PRE ? NQM : 1][NQM];
 
-        constexpr int ROWS = 10; // 640 dofs per pass: an 8x8-element patch of n_basis 4 (625) in one
         static_assert(!(NATIVE && PRE), "the native ordering is implemented for the chain form");
         // native ordering: local dofs [0, nown) are this patch's owned dofs at native positions own0 + i; the border dofs behind
         // them take their native position (gather) and their slot (write-out) from the patch's two short lists
-        int own0 = 0, nown = 0;
-        const int *bp = nullptr, *bs = nullptr;
-        if constexpr (NATIVE)
+        if constexpr (NATIVE && !FASTL)
         {
             own0 = A.own_off[patch];
             nown = A.own_off[patch + 1] - own0;
             bp = A.bpos + (size_t)patch * A.bstride;
             bs = A.bslot + (size_t)patch * A.bstride;
         }
-        const int bcap = A.bstride - 1;
         // Where the write-out sends its results (slot_of: the global dof of an owned local dof, -(slot) - 1 for a border dof).
         // The plan numbers a patch's owned dofs first, so for the rows of 64 local dofs below j_own = own_count / 64 the
         // destination IS the gather index and slot_of is not read at all: only its tail is (the rows holding border dofs),
@@ -805,7 +851,6 @@ namespace
             for (int j = 0; j < ROWS; ++j)
                 if (j >= j_own)
                     dest0[j] = slot[min(64 * j + lane, cap)];
-        const dbl2_t *X2 = reinterpret_cast<const dbl2_t *>(A.x);
         // Native gather, written WITHOUT wave-uniform branches (a conditional load is a basic block of its own to the compiler, which
         // then waits for every outstanding load at its end): the owned dofs are rows of 64 contiguous pairs at own0 + i (addresses
         // clamped, writes predicated), the border dofs a short list of native positions handled on its own.
@@ -912,7 +957,61 @@ namespace
                 }
             }
         };
-        if constexpr (NATIVE)
+        if constexpr (FASTL)
+        {
+            // straight-line: border values behind their positions, the first two slices behind those, the values pinned before
+            // the guarded LDS writes (the compiler would sink a row's request into its guard), then whatever a larger patch has left
+            dbl2_t xb[2];
+            xb[0] = X2[pbL[0]];
+            xb[1] = X2[pbL[1]];
+            if constexpr (X_FIRST)
+            {
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                load_stiff(0, g_first);
+                if constexpr (TWO_AHEAD)
+                    load_stiff(1, g_second);
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int j = 0; j < ROWS; ++j)
+                asm volatile("" : "+v"(xoL[j].x), "+v"(xoL[j].y));
+            asm volatile("" : "+v"(xb[0].x), "+v"(xb[0].y), "+v"(xb[1].x), "+v"(xb[1].y));
+#pragma unroll
+            for (int j = 0; j < ROWS; ++j)
+            {
+                const int i = 64 * j + lane;
+                if (i < nown)
+                {
+                    xy[i] = xoL[j].x;
+                    xy[ML + i] = xoL[j].y;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+            {
+                const int t = 64 * r + lane;
+                if (t < nbord)
+                {
+                    xy[nown + t] = xb[r].x;
+                    xy[ML + nown + t] = xb[r].y;
+                }
+            }
+            for (int i = 64 * ROWS + lane; i < nown; i += 64) // a patch larger than the regular block (irregular meshes)
+            {
+                const dbl2_t t2 = X2[own0 + i];
+                xy[i] = t2.x;
+                xy[ML + i] = t2.y;
+            }
+            for (int t = 128 + lane; t < nbord; t += 64)
+            {
+                const dbl2_t t2 = X2[bp[min(t, bcap)]];
+                xy[nown + t] = t2.x;
+                xy[ML + nown + t] = t2.y;
+            }
+        }
+        else if constexpr (NATIVE)
             native_gather();
         else
         {
