@@ -8,7 +8,8 @@
 //   helm_lane_kernel    n_basis 2-4, complex, general geometry, large plans: lane = element, both components per lane,
 //                       64-element patches, one wavefront each
 //   op_patch_kernel     n_basis 2-5, real   : one element per lane, one patch of 64 elements per wavefront
-//   helm_mfma_kernel    n_basis 6-8, complex: batches of 16 elements, 1-D contractions on v_mfma_f64_16x16x4_f64
+//   helm_mfma_kernel    n_basis 6-8, complex: batches of 16 elements, 1-D contractions on v_mfma_f64_4x4x4 / 16x16x4; n_basis 6, 7: the
+//                       batch's metric data in chunks requested one ahead and parked in LDS (no trip to memory inside a slice)
 //   op_mfma_kernel      n_basis 6-8, real   : the same for one operator
 //   helm_border_kernel / op_border_kernel: sums of the per-patch contributions at dofs shared by several patches
 //   repack_*, uniform_metric_kernel: plan construction
@@ -21,6 +22,8 @@
 //     from a uniform pointer (scalar registers) or MFMA A operands;
 //   * metric arrays are stored patch-major, structure-of-arrays, one contiguous block per quadrature slice, so every load
 //     instruction reads 256-512 contiguous bytes and DRAM pages are read whole; on affine meshes one copy serves all;
+//   * the complex kernels also take x / y in the plan's own ordering (pairs (u, v), a patch's owned dofs contiguous: 16-byte
+//     accesses at addresses known at kernel entry, lists for the border dofs only) -- what HelmholtzOperator::gmres iterates on;
 //   * dofs owned by one patch are stored straight to y; dofs on patch borders go to per-patch slots that a second small
 //     kernel sums in a fixed order.
 // Every apply is therefore bitwise reproducible and needs no zero-fill of y.
