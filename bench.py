@@ -142,6 +142,8 @@ def main() -> None:
     if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args.gpus))
 
+    # (multi-process GPU work on this pool needs dmabuf IPC; the image exports it, a bare launcher environment might not)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import torch.distributed as dist
 
